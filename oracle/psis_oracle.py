@@ -1,0 +1,230 @@
+"""CPU oracle for the PSIS-LOO hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+This module is a NumPy restatement of the arithmetic of the reference's hot path
+(jordandeklerk/pyloo, ``pyloo/psis.py``, ``pyloo/utils.py:305-359``,
+``pyloo/loo.py:286-342``, ``pyloo/sis.py:86-106``, ``pyloo/tis.py:91-120``).  It exists
+only so that ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` have something to check and time the HIP engine against.  Nothing under
+``pyloo_amd/`` imports it; the product path has no CPU fallback.
+
+Pinning: ``tests/test_oracle_golden.py`` checks every function below against the
+fixtures in ``tests/golden/*.npz``, which were produced by the reference's real functions
+(``tests/golden/make_golden.py``).  Parity is therefore pinned, not assumed.
+
+Structure: one Python iteration per observation, like the reference's
+``make_ufunc`` loop (``utils.py:171-175``) -- this is the "reference-faithful" mode that
+BASELINE.md section 4 asks to be timed as the CPU baseline.
+"""
+
+import numpy as np
+
+LOG_TINY = float(np.log(np.finfo(np.float64).tiny))  # psis.py:90 / base.py:142
+EPS = float(np.finfo(np.float64).eps)
+
+
+# --------------------------------------------------------------------------- helpers
+def tail_count(n_draws, reff=1.0):
+    """M = number of draws treated as the tail; ``cutoff_ind = -M - 1`` (base.py:139-141)."""
+    return int(np.ceil(min(n_draws / 5.0, 3.0 * (n_draws / reff) ** 0.5)))
+
+
+def good_k_threshold(n_draws):
+    """loo.py:249."""
+    return min(1.0 - 1.0 / np.log10(n_draws), 0.7)
+
+
+def lse(v, b_inv=None):
+    """Max-shifted log-sum-exp of a 1-D vector in the vector's own dtype (utils.py:305-359).
+
+    ``b_inv`` divides the sum (``lse(v, b_inv=S)`` is the log of the mean).  NaN in ``v``
+    gives NaN; an all ``-inf`` vector gives NaN (``-inf - -inf``), as in the reference.
+    """
+    v = np.asarray(v)
+    if v.dtype.kind in "iu":
+        v = v.astype(np.float64)
+    ftype = v.dtype.type
+    if b_inv is not None and b_inv == 0:
+        return np.inf
+    top = v.max()
+    shifted = v - top
+    np.exp(shifted, out=shifted)
+    total = ftype(np.log(shifted.sum(dtype=v.dtype)))
+    if b_inv is not None:
+        top = ftype(top - np.log(b_inv))  # utils.py:353-354 (max is adjusted in the array dtype)
+    return ftype(total + top)
+
+
+def gpd_fit(y):
+    """Zhang & Stephens (2009) empirical-Bayes GPD fit on ascending ``y``  (psis.py:163-208).
+
+    Returns ``(k, sigma)`` with the weakly-informative prior on k (10 pseudo draws at 0.5).
+    """
+    y = np.asarray(y)
+    n = y.shape[0]
+    m = 30 + int(n**0.5)  # psis.py:184
+    j = np.arange(1, m + 1, dtype=np.float64)
+    theta = 1.0 - np.sqrt(m / (j - 0.5))  # psis.py:186
+    theta = theta / (3 * y[int(n / 4 + 0.5) - 1])  # psis.py:187 (prior_bs = 3, first quartile)
+    theta = theta + 1.0 / y[-1]  # psis.py:188
+    kj = np.log1p(-theta[:, None] * y).mean(axis=1)  # psis.py:190
+    prof = n * (np.log(-(theta / kj)) - kj - 1.0)  # psis.py:191
+    w = 1.0 / np.exp(prof - prof[:, None]).sum(axis=1)  # psis.py:192
+    keep = w >= 10 * EPS  # psis.py:194-197
+    if not keep.all():
+        w = w[keep]
+        theta = theta[keep]
+    w = w / w.sum()  # psis.py:198
+    theta_hat = np.sum(theta * w)  # psis.py:201
+    k_hat = np.log1p(-theta_hat * y).mean()  # psis.py:203
+    sigma = -k_hat / theta_hat  # psis.py:205
+    k_hat = (n * k_hat + 10 * 0.5) / (n + 10)  # psis.py:206 (prior_k = 10)
+    return k_hat, sigma
+
+
+def gpd_quantile(p, k, sigma):
+    """Inverse CDF of the generalised Pareto distribution (psis.py:211-231)."""
+    p = np.asarray(p, dtype=np.float64)
+    q = np.full_like(p, np.nan)
+    if sigma <= 0:  # psis.py:214-215
+        return q
+    inside = (p > 0) & (p < 1)
+    if abs(k) < EPS:  # psis.py:218-219 / 224-225
+        q[inside] = -np.log1p(-p[inside])
+    else:
+        q[inside] = np.expm1(-k * np.log1p(-p[inside])) / k
+    q *= sigma
+    if not inside.all():  # psis.py:229-230
+        q[p == 0] = 0
+        q[p == 1] = np.inf if k >= 0 else -sigma / k
+    return q
+
+
+def psis_row(logw, M, floor=LOG_TINY, details=None):
+    """Pareto-smooth one vector of log importance ratios (psis.py:114-160).
+
+    Returns ``(lw, k)``: normalised smoothed log weights (same dtype as ``logw``) and the
+    tail-index estimate.  ``logw`` is not modified.  ``M`` is the tail count
+    (``cutoff_ind = -M - 1``).
+    """
+    x = np.array(logw, copy=True)
+    x -= x.max()  # psis.py:134
+    kth = np.sort(x)[-M - 1]  # psis.py:135-136; NaNs sort last like argsort
+    cut = max(kth, floor)  # python max: a NaN first argument wins (psis.py:136)
+    e_cut = np.exp(cut)  # psis.py:138
+    (where,) = np.nonzero(x > cut)  # psis.py:139 (strict: ties at the cutoff leave the tail)
+    n_tail = where.shape[0]
+    k = np.inf
+    sigma = np.nan
+    if n_tail > 4:  # psis.py:142-144
+        tail = x[where]
+        order = np.argsort(tail)  # psis.py:146
+        y = np.exp(tail) - e_cut  # psis.py:147
+        k, sigma = gpd_fit(y[order])  # psis.py:148
+        if np.isfinite(k):  # psis.py:150
+            p = np.arange(0.5, n_tail) / n_tail  # psis.py:153
+            smooth = np.log(gpd_quantile(p, k, sigma) + e_cut)  # psis.py:154-155
+            x[where[order]] = smooth  # psis.py:156 (rank-order scatter)
+            x[x > 0] = 0  # psis.py:157
+    x -= lse(x)  # psis.py:158
+    if details is not None:
+        details.update(xcutoff=cut, tail_len=n_tail, sigma=sigma)
+    return x, k
+
+
+def sis_row(logw):
+    """Plain self-normalised importance sampling (sis.py:86-106): (lw, ESS)."""
+    x = np.array(logw, copy=True)
+    x -= x.max()
+    x -= lse(x)
+    w = np.exp(x)
+    return x, 1.0 / np.sum(w**2)
+
+
+def tis_row(logw, n_draws=None):
+    """Truncated importance sampling, Ionides (2008) (tis.py:91-120): (lw, ESS)."""
+    x = np.array(logw, copy=True)
+    n_draws = x.shape[0] if n_draws is None else n_draws
+    x -= x.max()
+    log_z = lse(x) - np.log(n_draws)
+    x = np.minimum(x, log_z + 0.5 * np.log(n_draws))
+    x -= lse(x)
+    w = np.exp(x)
+    return x, 1.0 / np.sum(w**2)
+
+
+# --------------------------------------------------------------------- batched fronts
+def _rows(a):
+    a = np.asarray(a)
+    return a.reshape(-1, a.shape[-1]), a.shape[:-1]
+
+
+def psislw(log_weights, reff=1.0):
+    """(..., S) array -> (lw (..., S), k (...)); k is always float64 (psis.py:78-111)."""
+    flat, lead = _rows(log_weights)
+    M = tail_count(flat.shape[1], reff)
+    lw = np.empty_like(flat)
+    k = np.empty(flat.shape[0], dtype=np.float64)
+    with np.errstate(all="ignore"):
+        for i in range(flat.shape[0]):  # the loop of utils.py:171-175
+            lw[i], k[i] = psis_row(flat[i], M)
+    return lw.reshape(np.shape(log_weights)), k.reshape(lead)
+
+
+def importance_weights(log_weights, method="psis", reff=1.0):
+    """base.py:29-175 for ndarray input."""
+    method = str(getattr(method, "value", method)).lower()
+    if method == "psis":
+        return psislw(log_weights, reff)
+    if method not in ("sis", "tis"):
+        raise ValueError(f"Invalid method '{method}'. Must be one of: psis, sis, tis")
+    flat, lead = _rows(log_weights)
+    lw = np.empty_like(flat)
+    d = np.empty(flat.shape[0], dtype=np.float64)
+    with np.errstate(all="ignore"):
+        for i in range(flat.shape[0]):
+            lw[i], d[i] = sis_row(flat[i]) if method == "sis" else tis_row(flat[i], flat.shape[1])
+    return lw.reshape(np.shape(log_weights)), d.reshape(lead)
+
+
+def loo_pointwise(ll, reff=1.0, method="psis"):
+    """Per-observation pieces of loo.py:286-337 for an (N, S) log-likelihood matrix.
+
+    Returns dict(khat|ess, loo_i (scale "log"), lppd_i, lw).
+    """
+    ll = np.asarray(ll)
+    N, S = ll.shape
+    with np.errstate(all="ignore"):
+        lw, diag = importance_weights(-ll, method, reff)  # loo.py:286-288
+        lwll = lw + ll  # loo.py:289
+        loo_i = np.array([lse(r) for r in lwll], dtype=np.float64)  # loo.py:319-324
+        lppd_i = np.array([lse(r, b_inv=S) for r in ll], dtype=np.float64)  # loo.py:329-337
+    return {"diag": diag, "loo_i": loo_i, "lppd_i": lppd_i, "lw": lw}
+
+
+def loo_aggregate(loo_i, lppd_i, khat, n_draws, scale_value=1):
+    """loo.py:326-342 + 291-293 from pointwise values (``loo_i`` on the "log" scale)."""
+    li = scale_value * np.asarray(loo_i, dtype=np.float64)
+    n = li.size
+    elpd = li.sum()
+    se = (n * np.var(li)) ** 0.5
+    lppd = np.sum(lppd_i)
+    gk = good_k_threshold(n_draws)
+    return {
+        "elpd_loo": elpd,
+        "se": se,
+        "lppd": lppd,
+        "p_loo": lppd - elpd / scale_value,
+        "p_loo_se": np.sqrt(np.sum(np.var(li))),
+        "looic": -2 * elpd,
+        "looic_se": 2 * se,
+        "good_k": gk,
+        "n_high_k": int(np.sum(np.asarray(khat) > gk)),
+    }
+
+
+def loo_arrays(ll, reff=1.0, scale_value=1):
+    """Everything ``loo()`` computes from an (N, S) matrix, as plain numbers."""
+    pw = loo_pointwise(ll, reff)
+    out = loo_aggregate(pw["loo_i"], pw["lppd_i"], pw["diag"], ll.shape[1], scale_value)
+    out.update(khat=pw["diag"], loo_i=scale_value * pw["loo_i"], lppd_i=pw["lppd_i"], lw=pw["lw"])
+    return out
