@@ -1,0 +1,143 @@
+/*
+ * pyloo_amd.h -- C ABI of the MI355X-native PSIS-LOO engine (libpyloo_amd.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of jordandeklerk/pyloo that this
+ * project accelerates.  The reference has no FFI of its own: the seam
+ * is the Python call `wrap_xarray_ufunc(_psislw, ...)` that loops a 1-D NumPy routine over
+ * observations.  Each entry point below names the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns an int status (0 = PLA_OK,
+ *     negative = error) and never throws or aborts; pla_last_error() gives the text.
+ *   - the caller owns every buffer; inputs are const and never modified (the reference
+ *     deep-copies its input: psis.py:78, base.py:112); nothing is retained after return.
+ *   - numeric trouble is in-band exactly as in the reference: k = +inf when the tail has
+ *     <= 4 draws (psis.py:142-144), NaN weights for NaN rows, etc.  No status code for it.
+ *   - `mem_space` says where ALL data pointers of that call live: PLA_HOST (the library
+ *     stages through its own device buffers) or PLA_DEVICE (pointers are HIP device
+ *     pointers on the engine's device, work is enqueued on `stream`, no host sync).
+ *   - matrices are (n_obs, n_draws) with element strides (stride_obs, stride_draw) in
+ *     ELEMENTS; the fast path wants stride_draw == 1 ("S-contiguous", pyloo's stacked
+ *     `(*obs, __sample__)` view, loo.py:189).
+ *   - an engine is bound to one device; calls on one engine must be serialised by the
+ *     caller, different engines are independent (no hidden global state).
+ */
+#ifndef PYLOO_AMD_H
+#define PYLOO_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLA_ABI_VERSION 1
+
+/* status codes */
+#define PLA_OK 0
+#define PLA_ERR_ARG (-1)         /* bad argument (null pointer, n_draws < 2, bad enum ...) */
+#define PLA_ERR_HIP (-2)         /* a HIP runtime call failed (text in pla_last_error) */
+#define PLA_ERR_NOMEM (-3)       /* device or host allocation failed */
+#define PLA_ERR_UNSUPPORTED (-4) /* shape outside what the kernels support */
+#define PLA_ERR_NODEVICE (-5)    /* no usable AMD GPU */
+
+/* element type of the log-likelihood / log-weight matrix */
+#define PLA_F64 0
+#define PLA_F32 1 /* read as f32, all arithmetic in f64 (hard part 5) */
+
+#define PLA_HOST 0
+#define PLA_DEVICE 1
+
+/* importance-sampling method: ISMethod of base.py:18-23 */
+#define PLA_PSIS 0
+#define PLA_SIS 1
+#define PLA_TIS 2
+
+/* slots of the aggregate vector written by pla_psis_loo (all double) */
+#define PLA_AGG_N 0           /* number of observations reduced                          */
+#define PLA_AGG_SUM_LOO 1     /* sum_i loo_i                  (elpd_loo,  loo.py:326)      */
+#define PLA_AGG_M2_LOO 2      /* sum_i (loo_i - mean)^2       (se, p_loo_se: loo.py:327,340) */
+#define PLA_AGG_SUM_LPPD 3    /* sum_i lppd_i                 (loo.py:329-337)            */
+#define PLA_AGG_N_HIGH 4      /* #(khat > good_k)             (loo.py:292-293)            */
+#define PLA_AGG_N_NONFINITE 5 /* #(diagnostic not finite)                                 */
+#define PLA_AGG_MIN_DIAG 6    /* min_i diagnostic             (min ESS, loo.py:306)       */
+#define PLA_AGG_N_SLOW 7      /* rows that left the fast selection path (perf diagnostics) */
+#define PLA_AGG_COUNT 8
+
+typedef struct pla_engine pla_engine;
+
+/* library / device ------------------------------------------------------------------- */
+int pla_abi_version(void);
+const char *pla_last_error(void); /* thread-local, valid until the next failing call */
+int pla_device_count(int *count);
+
+/* One engine per (process, GPU): owns the small device workspace (no per-call hipMalloc on
+ * the PLA_DEVICE path, so calls can be captured in a hipGraph). */
+int pla_engine_create(int device, pla_engine **out);
+int pla_engine_destroy(pla_engine *eng);
+
+/* M of base.py:139-141 / psis.py:89:  ceil(min(S/5, 3*sqrt(S/reff)));  cutoff_ind = -M-1 */
+int pla_tail_count(int64_t n_draws, double reff, int64_t *tail_count);
+
+/*
+ * pla_psis_loo -- the fused per-observation LOO pass.
+ * Replaces loo.py:286-342: compute_importance_weights(-ll) -> `log_weights += ll` ->
+ * loo_i = scale * LSE_s(lw + ll) -> lppd_i = LSE_s(ll) - log S -> sums / variance / k counts,
+ * i.e. the three Python loops of utils.py:137-142,171-175 over psis.py:114-160 and
+ * utils.py:305-359, without ever materialising the (n_obs, n_draws) weight matrix.
+ *
+ *   ll          (n_obs, n_draws) log-likelihood, dtype PLA_F64 / PLA_F32, const
+ *   method      PLA_PSIS / PLA_SIS / PLA_TIS
+ *   tail_count  M from pla_tail_count (PSIS only; ignored otherwise)
+ *   scale_value 1, -1 or -2 (loo.py:195-200); loo_i and the aggregates carry it
+ *   good_k      threshold for PLA_AGG_N_HIGH (loo.py:249)
+ *   diag        [n_obs] khat (PSIS) or ESS (SIS/TIS), always double (base.py:125); may be NULL
+ *   loo_i       [n_obs] may be NULL          lppd_i [n_obs] may be NULL
+ *   agg         [PLA_AGG_COUNT] may be NULL
+ */
+int pla_psis_loo(pla_engine *eng, const void *ll, int dtype, int64_t n_obs, int64_t n_draws,
+                 int64_t stride_obs, int64_t stride_draw, int method, int64_t tail_count,
+                 double scale_value, double good_k, int mem_space, void *stream, double *diag,
+                 double *loo_i, double *lppd_i, double *agg);
+
+/*
+ * pla_importance_weights -- smoothed, truncated, normalised log weights AND the diagnostic.
+ * Replaces the batched dispatch of base.py:160-166 / psis.py:100-106 (the `_multi_ufunc`
+ * loop over `_psislw` / `_sislw` / `_tislw`).
+ *
+ *   logw   (n_obs, n_draws) log importance ratios (for LOO: -log_likelihood), const
+ *   lw_out (n_obs, n_draws) C-contiguous, same dtype as logw (base.py:125 empty_like)
+ *   diag   [n_obs] double
+ */
+int pla_importance_weights(pla_engine *eng, const void *logw, int dtype, int64_t n_obs,
+                           int64_t n_draws, int64_t stride_obs, int64_t stride_draw, int method,
+                           int64_t tail_count, int mem_space, void *stream, void *lw_out,
+                           double *diag);
+
+/*
+ * pla_reduce_pointwise -- only the reductions of loo.py:326-342,292-293 over pointwise
+ * vectors already on the device/host (used after sharded runs and by tests).
+ */
+int pla_reduce_pointwise(pla_engine *eng, const double *diag, const double *loo_i,
+                         const double *lppd_i, int64_t n_obs, double good_k, int mem_space,
+                         void *stream, double *agg);
+
+/* Timing of the dominant kernel, measured with hipEvents on the launch stream.
+ * enable != 0 brackets every main-kernel launch with events; pla_engine_kernel_ms returns the
+ * accumulated milliseconds and launch count since the last call (it synchronises the events). */
+int pla_engine_set_timing(pla_engine *eng, int enable);
+int pla_engine_kernel_ms(pla_engine *eng, double *total_ms, int64_t *launches);
+
+/* Synthetic benchmark input, generated on the device:
+ *   u = splitmix64(seed ^ (i*S + s)) -> 53-bit uniform in (0,1) -> E = -log1p(-u)
+ *   ll[i,s] = -k_i*E + c_i,  c_i = -1 - (i mod 7)/4,  k_i = k_lo + (k_hi-k_lo)*U(splitmix64(~seed ^ i))
+ *   rows with (i mod 10) in {0,3,6} draw k_i from [heavy_lo, heavy_hi) when heavy_hi > heavy_lo.
+ * row0 offsets the observation index so shards of one matrix can be generated per rank. */
+int pla_fill_synthetic(pla_engine *eng, void *ll_device, int dtype, int64_t n_obs, int64_t n_draws,
+                       int64_t row0, uint64_t seed, double k_lo, double k_hi, double heavy_lo,
+                       double heavy_hi, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYLOO_AMD_H */

@@ -1,0 +1,12 @@
+"""pyloo_amd -- MI355X-native PSIS-LOO engine behind pyloo's ``loo`` / ``psislw`` /
+``compute_importance_weights`` API.  The compute path is hand-written HIP (gfx950) reached
+through the C ABI in ``include/pyloo_amd.h``; there is no CPU fallback."""
+
+from .base import ISMethod, compute_importance_weights
+from .elpd import ELPDData
+from .loo import loo, loo_from_matrix
+from .psis import psislw
+from .rcparams import rcParams
+
+__all__ = ["ISMethod", "ELPDData", "compute_importance_weights", "loo", "loo_from_matrix", "psislw", "rcParams"]
+__version__ = "0.1.0"

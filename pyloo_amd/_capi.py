@@ -1,0 +1,95 @@
+"""ctypes binding of libpyloo_amd.so (include/pyloo_amd.h) -- the only way the Python front
+reaches the GPU.  There is deliberately no CPU fallback: a missing library or GPU raises."""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import LIB_PATH
+
+PLA_F64, PLA_F32 = 0, 1
+PLA_HOST, PLA_DEVICE = 0, 1
+PLA_PSIS, PLA_SIS, PLA_TIS = 0, 1, 2
+METHOD_CODES = {"psis": PLA_PSIS, "sis": PLA_SIS, "tis": PLA_TIS}
+AGG_N, AGG_SUM_LOO, AGG_M2_LOO, AGG_SUM_LPPD, AGG_N_HIGH, AGG_N_NONFINITE, AGG_MIN_DIAG, AGG_N_SLOW = range(8)
+AGG_COUNT = 8
+ABI_VERSION = 1
+
+# every symbol declared in include/pyloo_amd.h
+SYMBOLS = (
+    "pla_abi_version", "pla_last_error", "pla_device_count", "pla_engine_create", "pla_engine_destroy",
+    "pla_tail_count", "pla_psis_loo", "pla_importance_weights", "pla_reduce_pointwise",
+    "pla_engine_set_timing", "pla_engine_kernel_ms", "pla_fill_synthetic",
+)
+
+
+class EngineError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"libpyloo_amd status {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree library; fail loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP engine has not been built "
+            "(run `python -m pyloo_amd.build`).  pyloo_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    i64, dbl, vp, ci = C.c_int64, C.c_double, C.c_void_p, C.c_int
+    lib.pla_abi_version.restype = ci
+    lib.pla_last_error.restype = C.c_char_p
+    lib.pla_device_count.argtypes = [C.POINTER(ci)]
+    lib.pla_engine_create.argtypes = [ci, C.POINTER(vp)]
+    lib.pla_engine_destroy.argtypes = [vp]
+    lib.pla_tail_count.argtypes = [i64, dbl, C.POINTER(i64)]
+    lib.pla_psis_loo.argtypes = [vp, vp, ci, i64, i64, i64, i64, ci, i64, dbl, dbl, ci, vp, vp, vp, vp, vp]
+    lib.pla_importance_weights.argtypes = [vp, vp, ci, i64, i64, i64, i64, ci, i64, ci, vp, vp, vp]
+    lib.pla_reduce_pointwise.argtypes = [vp, vp, vp, vp, i64, dbl, ci, vp, vp]
+    lib.pla_engine_set_timing.argtypes = [vp, ci]
+    lib.pla_engine_kernel_ms.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
+    lib.pla_fill_synthetic.argtypes = [vp, vp, ci, i64, i64, i64, C.c_uint64, dbl, dbl, dbl, dbl, vp]
+    for name in SYMBOLS:
+        getattr(lib, name)  # AttributeError if the header and the library disagree
+        if name != "pla_last_error":
+            getattr(lib, name).restype = ci
+    if lib.pla_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libpyloo_amd ABI {lib.pla_abi_version()} != expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise EngineError(code, load_library().pla_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load_library().pla_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def tail_count(n_draws, reff):
+    out = C.c_int64(0)
+    check(load_library().pla_tail_count(int(n_draws), float(reff), C.byref(out)))
+    return out.value
+
+
+def dtype_code(dt):
+    dt = np.dtype(dt)
+    if dt == np.float64:
+        return PLA_F64
+    if dt == np.float32:
+        return PLA_F32
+    raise TypeError(f"unsupported dtype {dt}")

@@ -1,0 +1,418 @@
+// C ABI of libpyloo_amd.so (see include/pyloo_amd.h).  Host code only: argument checks,
+// host<->device staging for PLA_HOST callers, kernel launches on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/pyloo_amd.h"
+#include "pla_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define PLA_HIP(call)                                                                     \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(e_ == hipErrorOutOfMemory ? PLA_ERR_NOMEM : PLA_ERR_HIP, "%s: %s", #call, \
+                  hipGetErrorString(e_));                                                 \
+  } while (0)
+
+int pow2_at_least(int64_t n) {
+  int p = 8;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+}  // namespace
+
+struct pla_engine {
+  int device = 0;
+  unsigned long long* counters = nullptr;  // [4] device
+  // staging for PLA_HOST callers (grown on demand)
+  void* d_in = nullptr;
+  size_t d_in_bytes = 0;
+  void* d_lw = nullptr;
+  size_t d_lw_bytes = 0;
+  double* d_pw = nullptr;  // 3 * n doubles + agg
+  size_t d_pw_elems = 0;
+  // timing of the main kernel
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double acc_ms = 0.0;
+  int64_t launches = 0;
+  bool pending = false;
+};
+
+namespace {
+
+int grow(void** p, size_t* have, size_t want) {
+  if (*have >= want) return PLA_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *have = 0;
+  hipError_t e = hipMalloc(p, want);
+  if (e != hipSuccess) return fail(PLA_ERR_NOMEM, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+  *have = want;
+  return PLA_OK;
+}
+
+int check_common(pla_engine* eng, const void* in, int dtype, int64_t n_obs, int64_t n_draws,
+                 int64_t stride_obs, int64_t stride_draw, int method, int64_t tail_count, int mem_space) {
+  if (!eng) return fail(PLA_ERR_ARG, "engine is NULL");
+  if (dtype != PLA_F64 && dtype != PLA_F32) return fail(PLA_ERR_ARG, "dtype must be PLA_F64 or PLA_F32");
+  if (mem_space != PLA_HOST && mem_space != PLA_DEVICE) return fail(PLA_ERR_ARG, "bad mem_space");
+  if (method != PLA_PSIS && method != PLA_SIS && method != PLA_TIS) return fail(PLA_ERR_ARG, "bad method");
+  if (n_obs < 0) return fail(PLA_ERR_ARG, "n_obs < 0");
+  if (n_obs > 0 && !in) return fail(PLA_ERR_ARG, "input pointer is NULL");
+  if (n_draws < 1 || n_draws > (int64_t)1 << 30) return fail(PLA_ERR_ARG, "n_draws out of range");
+  if (stride_draw == 0 || stride_obs < 0 || stride_draw < 0) return fail(PLA_ERR_ARG, "bad strides");
+  if (method == PLA_PSIS) {
+    // x_sorted[-M-1] must exist (numpy raises IndexError otherwise: psis.py:136)
+    if (tail_count < 1 || tail_count + 1 > n_draws)
+      return fail(PLA_ERR_ARG, "tail_count %lld needs at least %lld draws, got %lld", (long long)tail_count,
+                  (long long)tail_count + 1, (long long)n_draws);
+    if (tail_count > pla::max_tail_count())
+      return fail(PLA_ERR_UNSUPPORTED, "tail_count %lld exceeds the LDS tail capacity %d", (long long)tail_count,
+                  pla::max_tail_count());
+  }
+  return PLA_OK;
+}
+
+struct TimedLaunch {  // brackets the main kernel with events when timing is on
+  pla_engine* e;
+  hipStream_t s;
+  TimedLaunch(pla_engine* e_, hipStream_t s_) : e(e_), s(s_) {
+    if (e->timing) {
+      if (e->pending) flush(e);
+      (void)hipEventRecord(e->ev0, s);
+    }
+  }
+  ~TimedLaunch() {
+    if (e->timing) {
+      (void)hipEventRecord(e->ev1, s);
+      e->pending = true;
+    }
+  }
+  static void flush(pla_engine* e) {
+    if (!e->pending) return;
+    float ms = 0.f;
+    if (hipEventSynchronize(e->ev1) == hipSuccess && hipEventElapsedTime(&ms, e->ev0, e->ev1) == hipSuccess) {
+      e->acc_ms += ms;
+      e->launches += 1;
+    }
+    e->pending = false;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int pla_abi_version(void) { return PLA_ABI_VERSION; }
+
+const char* pla_last_error(void) { return g_err; }
+
+int pla_device_count(int* count) {
+  if (!count) return fail(PLA_ERR_ARG, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(PLA_ERR_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return PLA_OK;
+}
+
+int pla_engine_create(int device, pla_engine** out) {
+  if (!out) return fail(PLA_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(PLA_ERR_NODEVICE, "no HIP device available");
+  if (device < 0 || device >= n) return fail(PLA_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
+  PLA_HIP(hipSetDevice(device));
+  pla_engine* e = new (std::nothrow) pla_engine();
+  if (!e) return fail(PLA_ERR_NOMEM, "out of host memory");
+  e->device = device;
+  hipError_t he = hipMalloc((void**)&e->counters, 4 * sizeof(unsigned long long));
+  if (he == hipSuccess) he = hipMemset(e->counters, 0, 4 * sizeof(unsigned long long));
+  if (he == hipSuccess) he = hipEventCreate(&e->ev0);
+  if (he == hipSuccess) he = hipEventCreate(&e->ev1);
+  if (he != hipSuccess) {
+    pla_engine_destroy(e);
+    return fail(PLA_ERR_HIP, "engine setup: %s", hipGetErrorString(he));
+  }
+  *out = e;
+  return PLA_OK;
+}
+
+int pla_engine_destroy(pla_engine* e) {
+  if (!e) return PLA_OK;
+  (void)hipSetDevice(e->device);
+  if (e->counters) (void)hipFree(e->counters);
+  if (e->d_in) (void)hipFree(e->d_in);
+  if (e->d_lw) (void)hipFree(e->d_lw);
+  if (e->d_pw) (void)hipFree(e->d_pw);
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  delete e;
+  return PLA_OK;
+}
+
+int pla_tail_count(int64_t n_draws, double reff, int64_t* tail_count) {
+  if (!tail_count) return fail(PLA_ERR_ARG, "tail_count is NULL");
+  if (n_draws < 1 || !(reff > 0.0)) return fail(PLA_ERR_ARG, "need n_draws >= 1 and reff > 0");
+  const double a = (double)n_draws / 5.0;
+  const double b = 3.0 * std::sqrt((double)n_draws / reff);  // base.py:139-141
+  *tail_count = (int64_t)std::ceil(a < b ? a : b);
+  return PLA_OK;
+}
+
+int pla_engine_set_timing(pla_engine* e, int enable) {
+  if (!e) return fail(PLA_ERR_ARG, "engine is NULL");
+  TimedLaunch::flush(e);
+  e->timing = enable != 0;
+  return PLA_OK;
+}
+
+int pla_engine_kernel_ms(pla_engine* e, double* total_ms, int64_t* launches) {
+  if (!e) return fail(PLA_ERR_ARG, "engine is NULL");
+  TimedLaunch::flush(e);
+  if (total_ms) *total_ms = e->acc_ms;
+  if (launches) *launches = e->launches;
+  e->acc_ms = 0.0;
+  e->launches = 0;
+  return PLA_OK;
+}
+
+int pla_reduce_pointwise(pla_engine* eng, const double* diag, const double* loo_i, const double* lppd_i,
+                         int64_t n_obs, double good_k, int mem_space, void* stream, double* agg) {
+  if (!eng) return fail(PLA_ERR_ARG, "engine is NULL");
+  if (!agg) return fail(PLA_ERR_ARG, "agg is NULL");
+  if (n_obs < 0) return fail(PLA_ERR_ARG, "n_obs < 0");
+  if (mem_space != PLA_HOST && mem_space != PLA_DEVICE) return fail(PLA_ERR_ARG, "bad mem_space");
+  PLA_HIP(hipSetDevice(eng->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (mem_space == PLA_DEVICE) {
+    pla::ReduceParams rp{diag, loo_i, lppd_i, n_obs, good_k, agg};
+    PLA_HIP(pla::launch_reduce(rp, s));
+    return PLA_OK;
+  }
+  const size_t need = (size_t)(3 * n_obs + PLA_AGG_COUNT);
+  size_t have_b = eng->d_pw_elems * sizeof(double);
+  int rc = grow((void**)&eng->d_pw, &have_b, need * sizeof(double));
+  eng->d_pw_elems = have_b / sizeof(double);
+  if (rc) return rc;
+  double* d = eng->d_pw;
+  double *dd = nullptr, *dl = nullptr, *dp = nullptr;
+  if (diag) { dd = d; PLA_HIP(hipMemcpyAsync(dd, diag, n_obs * sizeof(double), hipMemcpyHostToDevice, s)); }
+  if (loo_i) { dl = d + n_obs; PLA_HIP(hipMemcpyAsync(dl, loo_i, n_obs * sizeof(double), hipMemcpyHostToDevice, s)); }
+  if (lppd_i) { dp = d + 2 * n_obs; PLA_HIP(hipMemcpyAsync(dp, lppd_i, n_obs * sizeof(double), hipMemcpyHostToDevice, s)); }
+  double* dagg = d + 3 * n_obs;
+  pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, dagg};
+  PLA_HIP(pla::launch_reduce(rp, s));
+  PLA_HIP(hipMemcpyAsync(agg, dagg, PLA_AGG_COUNT * sizeof(double), hipMemcpyDeviceToHost, s));
+  PLA_HIP(hipStreamSynchronize(s));
+  return PLA_OK;
+}
+
+int pla_psis_loo(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int64_t n_draws, int64_t stride_obs,
+                 int64_t stride_draw, int method, int64_t tail_count, double scale_value, double good_k,
+                 int mem_space, void* stream, double* diag, double* loo_i, double* lppd_i, double* agg) {
+  int rc = check_common(eng, ll, dtype, n_obs, n_draws, stride_obs, stride_draw, method, tail_count, mem_space);
+  if (rc) return rc;
+  PLA_HIP(hipSetDevice(eng->device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t esz = dtype == PLA_F64 ? 8 : 4;
+
+  pla::RowsParams p{};
+  p.n_obs = n_obs;
+  p.n_draws = (int)n_draws;
+  p.method = method;
+  p.tail_count = method == PLA_PSIS ? (int)tail_count : 0;
+  p.tail_cap = pow2_at_least(p.tail_count);
+  p.scale_value = scale_value;
+  p.counters = eng->counters;
+
+  if (mem_space == PLA_DEVICE) {
+    // agg needs the pointwise loo_i: use the caller's vectors, or the engine scratch
+    double *dd = diag, *dl = loo_i, *dp = lppd_i;
+    if (agg && (!dd || !dl || !dp)) {
+      size_t have_b = eng->d_pw_elems * sizeof(double);
+      rc = grow((void**)&eng->d_pw, &have_b, (size_t)(3 * n_obs + PLA_AGG_COUNT) * sizeof(double));
+      eng->d_pw_elems = have_b / sizeof(double);
+      if (rc) return rc;
+      if (!dd) dd = eng->d_pw;
+      if (!dl) dl = eng->d_pw + n_obs;
+      if (!dp) dp = eng->d_pw + 2 * n_obs;
+    }
+    p.in = ll;
+    p.stride_obs = stride_obs;
+    p.stride_draw = stride_draw;
+    p.diag = dd;
+    p.loo_i = dl;
+    p.lppd_i = dp;
+    {
+      TimedLaunch t(eng, s);
+      PLA_HIP(pla::launch_rows(p, dtype, false, s));
+    }
+    if (agg) {
+      pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, agg};
+      PLA_HIP(pla::launch_reduce(rp, s));
+    }
+    return PLA_OK;
+  }
+
+  // ---- PLA_HOST: stage row blocks through the device --------------------------------------
+  {
+    size_t have_b = eng->d_pw_elems * sizeof(double);
+    rc = grow((void**)&eng->d_pw, &have_b, (size_t)(3 * n_obs + PLA_AGG_COUNT) * sizeof(double));
+    eng->d_pw_elems = have_b / sizeof(double);
+    if (rc) return rc;
+  }
+  double* dd = eng->d_pw;
+  double* dl = eng->d_pw + n_obs;
+  double* dp = eng->d_pw + 2 * n_obs;
+  double* dagg = eng->d_pw + 3 * n_obs;
+  const size_t row_bytes = (size_t)n_draws * esz;
+  int64_t rows_per_chunk = (int64_t)(((size_t)1 << 30) / (row_bytes ? row_bytes : 1));
+  if (rows_per_chunk < 1) rows_per_chunk = 1;
+  if (rows_per_chunk > n_obs) rows_per_chunk = n_obs;
+  if (n_obs > 0) {
+    rc = grow(&eng->d_in, &eng->d_in_bytes, (size_t)rows_per_chunk * row_bytes);
+    if (rc) return rc;
+  }
+  for (int64_t r0 = 0; r0 < n_obs; r0 += rows_per_chunk) {
+    const int64_t nr = (n_obs - r0 < rows_per_chunk) ? (n_obs - r0) : rows_per_chunk;
+    const char* src = (const char*)ll + (size_t)r0 * stride_obs * esz;
+    // pack to (nr, S) contiguous on the device; strided sources use a pitched copy
+    if (stride_draw == 1) {
+      PLA_HIP(hipMemcpy2DAsync(eng->d_in, row_bytes, src, (size_t)stride_obs * esz, row_bytes, (size_t)nr,
+                               hipMemcpyHostToDevice, s));
+      p.stride_obs = n_draws;
+      p.stride_draw = 1;
+    } else {
+      return fail(PLA_ERR_UNSUPPORTED, "PLA_HOST input needs stride_draw == 1 (transpose on the host)");
+    }
+    p.in = eng->d_in;
+    p.n_obs = nr;
+    p.diag = dd + r0;
+    p.loo_i = dl + r0;
+    p.lppd_i = dp + r0;
+    {
+      TimedLaunch t(eng, s);
+      PLA_HIP(pla::launch_rows(p, dtype, false, s));
+    }
+    PLA_HIP(hipStreamSynchronize(s));  // the staging buffer is reused by the next chunk
+  }
+  if (n_obs > 0) {
+    if (diag) PLA_HIP(hipMemcpyAsync(diag, dd, n_obs * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (loo_i) PLA_HIP(hipMemcpyAsync(loo_i, dl, n_obs * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (lppd_i) PLA_HIP(hipMemcpyAsync(lppd_i, dp, n_obs * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  if (agg) {
+    pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, dagg};
+    PLA_HIP(pla::launch_reduce(rp, s));
+    PLA_HIP(hipMemcpyAsync(agg, dagg, PLA_AGG_COUNT * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  PLA_HIP(hipStreamSynchronize(s));
+  return PLA_OK;
+}
+
+int pla_importance_weights(pla_engine* eng, const void* logw, int dtype, int64_t n_obs, int64_t n_draws,
+                           int64_t stride_obs, int64_t stride_draw, int method, int64_t tail_count,
+                           int mem_space, void* stream, void* lw_out, double* diag) {
+  int rc = check_common(eng, logw, dtype, n_obs, n_draws, stride_obs, stride_draw, method, tail_count, mem_space);
+  if (rc) return rc;
+  if (n_obs > 0 && !lw_out) return fail(PLA_ERR_ARG, "lw_out is NULL");
+  PLA_HIP(hipSetDevice(eng->device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t esz = dtype == PLA_F64 ? 8 : 4;
+
+  pla::RowsParams p{};
+  p.n_obs = n_obs;
+  p.n_draws = (int)n_draws;
+  p.method = method;
+  p.tail_count = method == PLA_PSIS ? (int)tail_count : 0;
+  p.tail_cap = pow2_at_least(p.tail_count);
+  p.scale_value = 1.0;
+  p.counters = eng->counters;
+
+  if (mem_space == PLA_DEVICE) {
+    p.in = logw;
+    p.stride_obs = stride_obs;
+    p.stride_draw = stride_draw;
+    p.diag = diag;
+    p.lw_out = lw_out;
+    TimedLaunch t(eng, s);
+    PLA_HIP(pla::launch_rows(p, dtype, true, s));
+    return PLA_OK;
+  }
+
+  if (stride_draw != 1) return fail(PLA_ERR_UNSUPPORTED, "PLA_HOST input needs stride_draw == 1 (transpose on the host)");
+  const size_t row_bytes = (size_t)n_draws * esz;
+  int64_t rows_per_chunk = (int64_t)(((size_t)1 << 30) / (row_bytes ? row_bytes : 1));
+  if (rows_per_chunk < 1) rows_per_chunk = 1;
+  if (rows_per_chunk > n_obs) rows_per_chunk = n_obs;
+  if (n_obs == 0) return PLA_OK;
+  rc = grow(&eng->d_in, &eng->d_in_bytes, (size_t)rows_per_chunk * row_bytes);
+  if (rc) return rc;
+  rc = grow(&eng->d_lw, &eng->d_lw_bytes, (size_t)rows_per_chunk * row_bytes);
+  if (rc) return rc;
+  {
+    size_t have_b = eng->d_pw_elems * sizeof(double);
+    rc = grow((void**)&eng->d_pw, &have_b, (size_t)(3 * n_obs + PLA_AGG_COUNT) * sizeof(double));
+    eng->d_pw_elems = have_b / sizeof(double);
+    if (rc) return rc;
+  }
+  for (int64_t r0 = 0; r0 < n_obs; r0 += rows_per_chunk) {
+    const int64_t nr = (n_obs - r0 < rows_per_chunk) ? (n_obs - r0) : rows_per_chunk;
+    const char* src = (const char*)logw + (size_t)r0 * stride_obs * esz;
+    PLA_HIP(hipMemcpy2DAsync(eng->d_in, row_bytes, src, (size_t)stride_obs * esz, row_bytes, (size_t)nr,
+                             hipMemcpyHostToDevice, s));
+    p.in = eng->d_in;
+    p.stride_obs = n_draws;
+    p.stride_draw = 1;
+    p.n_obs = nr;
+    p.diag = eng->d_pw + r0;
+    p.lw_out = eng->d_lw;
+    {
+      TimedLaunch t(eng, s);
+      PLA_HIP(pla::launch_rows(p, dtype, true, s));
+    }
+    PLA_HIP(hipMemcpyAsync((char*)lw_out + (size_t)r0 * row_bytes, eng->d_lw, (size_t)nr * row_bytes,
+                           hipMemcpyDeviceToHost, s));
+    PLA_HIP(hipStreamSynchronize(s));
+  }
+  if (diag) PLA_HIP(hipMemcpyAsync(diag, eng->d_pw, n_obs * sizeof(double), hipMemcpyDeviceToHost, s));
+  PLA_HIP(hipStreamSynchronize(s));
+  return PLA_OK;
+}
+
+int pla_fill_synthetic(pla_engine* eng, void* ll_device, int dtype, int64_t n_obs, int64_t n_draws, int64_t row0,
+                       uint64_t seed, double k_lo, double k_hi, double heavy_lo, double heavy_hi, void* stream) {
+  if (!eng) return fail(PLA_ERR_ARG, "engine is NULL");
+  if (dtype != PLA_F64 && dtype != PLA_F32) return fail(PLA_ERR_ARG, "dtype must be PLA_F64 or PLA_F32");
+  if (n_obs < 0 || n_draws < 1) return fail(PLA_ERR_ARG, "bad shape");
+  if (n_obs > 0 && !ll_device) return fail(PLA_ERR_ARG, "ll_device is NULL");
+  PLA_HIP(hipSetDevice(eng->device));
+  PLA_HIP(pla::launch_fill_synthetic(ll_device, dtype, n_obs, n_draws, row0, seed, k_lo, k_hi, heavy_lo, heavy_hi,
+                                     (hipStream_t)stream));
+  return PLA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// Host-visible launch interface of the HIP kernels (internal to libpyloo_amd.so).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pla {
+
+struct RowsParams {
+  const void* in;       // (n_obs, n_draws) log-likelihood (LOO mode) or log ratios (LW mode)
+  int64_t n_obs;
+  int n_draws;
+  int64_t stride_obs;   // elements
+  int64_t stride_draw;  // elements
+  int method;           // PLA_PSIS / PLA_SIS / PLA_TIS
+  int tail_count;       // M (PSIS)
+  int tail_cap;         // power of two >= M: LDS tail capacity
+  double scale_value;   // LOO mode
+  double* diag;         // [n_obs] or null
+  double* loo_i;        // [n_obs] or null (LOO mode)
+  double* lppd_i;       // [n_obs] or null (LOO mode)
+  void* lw_out;         // (n_obs, n_draws) contiguous, input dtype (LW mode)
+  unsigned long long* counters;  // [4] device counters (slow rows, ...), may be null
+};
+
+struct ReduceParams {
+  const double* diag;
+  const double* loo_i;
+  const double* lppd_i;
+  int64_t n_obs;
+  double good_k;
+  double* agg;  // [PLA_AGG_COUNT]
+};
+
+// returns hipSuccess or the launch error; never synchronises
+hipError_t launch_rows(const RowsParams& p, int dtype, bool lw_mode, hipStream_t stream);
+hipError_t launch_reduce(const ReduceParams& p, hipStream_t stream);
+hipError_t launch_fill_synthetic(void* ll, int dtype, int64_t n_obs, int64_t n_draws, int64_t row0,
+                                 uint64_t seed, double k_lo, double k_hi, double heavy_lo,
+                                 double heavy_hi, hipStream_t stream);
+// largest tail count the kernels accept
+int max_tail_count();
+
+}  // namespace pla

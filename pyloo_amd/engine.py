@@ -1,0 +1,191 @@
+"""Python handle on one ``pla_engine`` (one GPU) and the array plumbing around the C ABI.
+
+Inputs may be NumPy arrays (host memory: the library stages them through the device) or
+torch CUDA tensors (device memory: zero copies, work is enqueued on torch's current stream
+and results come back as CUDA tensors).  torch is used only for device memory and streams.
+"""
+
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _capi
+from ._capi import AGG_COUNT, METHOD_CODES, PLA_DEVICE, PLA_HOST, check, dtype_code, load_library
+
+_engines = {}
+_lock = threading.Lock()
+
+
+def _is_torch_tensor(a):
+    return type(a).__module__.split(".")[0] == "torch" and hasattr(a, "data_ptr")
+
+
+class Engine:
+    """One engine per (process, device).  Use :func:`get_engine`."""
+
+    def __init__(self, device=0):
+        lib = load_library()
+        n = _capi.device_count()
+        if n <= 0:
+            raise RuntimeError(
+                "pyloo_amd needs an AMD GPU (MI355X / gfx950): no HIP device is visible. "
+                "There is no CPU fallback."
+            )
+        h = C.c_void_p()
+        check(lib.pla_engine_create(int(device), C.byref(h)))
+        self._lib = lib
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pla_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        import torch
+
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _as_2d_host(a):
+        a = np.asarray(a)
+        if a.dtype not in (np.float64, np.float32):
+            a = a.astype(np.float64)
+        if a.ndim != 2:
+            raise ValueError("expected a 2-D (n_obs, n_draws) array")
+        if a.shape[1] > 1 and a.strides[1] != a.itemsize:
+            a = np.ascontiguousarray(a)
+        if a.shape[0] > 1 and (a.strides[0] % a.itemsize != 0 or a.strides[0] < 0):
+            a = np.ascontiguousarray(a)
+        return a
+
+    # ------------------------------------------------------------------ LOO pass
+    def psis_loo(self, ll, tail_count=0, method="psis", scale_value=1.0, good_k=0.7, pointwise=True, aggregate=True):
+        """Fused pass over an (n_obs, n_draws) log-likelihood matrix (``pla_psis_loo``).
+
+        Returns ``dict(diag, loo_i, lppd_i, agg)`` -- NumPy arrays for NumPy input, CUDA tensors
+        for CUDA-tensor input (``agg`` included; nothing is synchronised in that case).
+        """
+        mcode = METHOD_CODES[method]
+        if _is_torch_tensor(ll):
+            return self._psis_loo_device(ll, tail_count, mcode, scale_value, good_k, pointwise, aggregate)
+        a = self._as_2d_host(ll)
+        n, s = a.shape
+        so = a.strides[0] // a.itemsize if n > 1 else s
+        diag = np.empty(n) if pointwise else None
+        loo_i = np.empty(n) if pointwise else None
+        lppd_i = np.empty(n) if pointwise else None
+        agg = np.zeros(AGG_COUNT) if aggregate else None
+        p = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)  # noqa: E731
+        check(self._lib.pla_psis_loo(self._h, a.ctypes.data_as(C.c_void_p), dtype_code(a.dtype), n, s, so, 1,
+                                     mcode, int(tail_count), float(scale_value), float(good_k), PLA_HOST,
+                                     None, p(diag), p(loo_i), p(lppd_i), p(agg)))
+        return {"diag": diag, "loo_i": loo_i, "lppd_i": lppd_i, "agg": agg}
+
+    def _psis_loo_device(self, t, tail_count, mcode, scale_value, good_k, pointwise, aggregate):
+        import torch
+
+        if t.dim() != 2 or not t.is_cuda:
+            raise ValueError("expected a 2-D CUDA tensor")
+        if t.dtype not in (torch.float64, torch.float32):
+            raise TypeError(f"unsupported dtype {t.dtype}")
+        n, s = t.shape
+        dev = t.device
+        diag = torch.empty(n, dtype=torch.float64, device=dev) if (pointwise or aggregate) else None
+        loo_i = torch.empty(n, dtype=torch.float64, device=dev) if (pointwise or aggregate) else None
+        lppd_i = torch.empty(n, dtype=torch.float64, device=dev) if (pointwise or aggregate) else None
+        agg = torch.zeros(AGG_COUNT, dtype=torch.float64, device=dev) if aggregate else None
+        p = lambda x: None if x is None else C.c_void_p(x.data_ptr())  # noqa: E731
+        code = _capi.PLA_F64 if t.dtype == torch.float64 else _capi.PLA_F32
+        check(self._lib.pla_psis_loo(self._h, C.c_void_p(t.data_ptr()), code, n, s, t.stride(0), t.stride(1),
+                                     mcode, int(tail_count), float(scale_value), float(good_k), PLA_DEVICE,
+                                     self._stream(), p(diag), p(loo_i), p(lppd_i), p(agg)))
+        return {"diag": diag, "loo_i": loo_i, "lppd_i": lppd_i, "agg": agg}
+
+    # ------------------------------------------------------------------ weights pass
+    def importance_weights(self, logw, tail_count=0, method="psis"):
+        """(n_obs, n_draws) log ratios -> (lw, diag) (``pla_importance_weights``)."""
+        mcode = METHOD_CODES[method]
+        if _is_torch_tensor(logw):
+            import torch
+
+            t = logw
+            n, s = t.shape
+            lw = torch.empty((n, s), dtype=t.dtype, device=t.device)
+            diag = torch.empty(n, dtype=torch.float64, device=t.device)
+            code = _capi.PLA_F64 if t.dtype == torch.float64 else _capi.PLA_F32
+            check(self._lib.pla_importance_weights(self._h, C.c_void_p(t.data_ptr()), code, n, s, t.stride(0),
+                                                   t.stride(1), mcode, int(tail_count), PLA_DEVICE, self._stream(),
+                                                   C.c_void_p(lw.data_ptr()), C.c_void_p(diag.data_ptr())))
+            return lw, diag
+        a = self._as_2d_host(logw)
+        n, s = a.shape
+        so = a.strides[0] // a.itemsize if n > 1 else s
+        lw = np.empty((n, s), dtype=a.dtype)
+        diag = np.empty(n)
+        check(self._lib.pla_importance_weights(self._h, a.ctypes.data_as(C.c_void_p), dtype_code(a.dtype), n, s, so, 1,
+                                               mcode, int(tail_count), PLA_HOST, None,
+                                               lw.ctypes.data_as(C.c_void_p), diag.ctypes.data_as(C.c_void_p)))
+        return lw, diag
+
+    # ------------------------------------------------------------------ reductions
+    def reduce_pointwise(self, diag, loo_i, lppd_i, good_k):
+        if _is_torch_tensor(loo_i):
+            import torch
+
+            agg = torch.zeros(AGG_COUNT, dtype=torch.float64, device=loo_i.device)
+            check(self._lib.pla_reduce_pointwise(self._h, C.c_void_p(diag.data_ptr()), C.c_void_p(loo_i.data_ptr()),
+                                                 C.c_void_p(lppd_i.data_ptr()), loo_i.numel(), float(good_k),
+                                                 PLA_DEVICE, self._stream(), C.c_void_p(agg.data_ptr())))
+            return agg
+        d, l, p = (np.ascontiguousarray(x, dtype=np.float64) for x in (diag, loo_i, lppd_i))
+        agg = np.zeros(AGG_COUNT)
+        check(self._lib.pla_reduce_pointwise(self._h, d.ctypes.data_as(C.c_void_p), l.ctypes.data_as(C.c_void_p),
+                                             p.ctypes.data_as(C.c_void_p), l.size, float(good_k), PLA_HOST, None,
+                                             agg.ctypes.data_as(C.c_void_p)))
+        return agg
+
+    # ------------------------------------------------------------------ bench helpers
+    def fill_synthetic(self, t, seed, row0=0, k_lo=0.05, k_hi=0.60, heavy_lo=0.0, heavy_hi=0.0):
+        import torch
+
+        code = _capi.PLA_F64 if t.dtype == torch.float64 else _capi.PLA_F32
+        n, s = t.shape
+        assert t.is_contiguous()
+        check(self._lib.pla_fill_synthetic(self._h, C.c_void_p(t.data_ptr()), code, n, s, int(row0), int(seed),
+                                           k_lo, k_hi, heavy_lo, heavy_hi, self._stream()))
+
+    def set_timing(self, on):
+        check(self._lib.pla_engine_set_timing(self._h, 1 if on else 0))
+
+    def kernel_ms(self):
+        ms, k = C.c_double(0), C.c_int64(0)
+        check(self._lib.pla_engine_kernel_ms(self._h, C.byref(ms), C.byref(k)))
+        return ms.value, k.value
+
+
+def get_engine(device=None):
+    """Process-wide engine for ``device`` (default: torch's current CUDA device, else 0)."""
+    if device is None:
+        device = 0
+        try:
+            import torch
+
+            if torch.cuda.is_available():
+                device = torch.cuda.current_device()
+        except Exception:
+            device = 0
+    with _lock:
+        eng = _engines.get(device)
+        if eng is None:
+            eng = _engines[device] = Engine(device)
+        return eng

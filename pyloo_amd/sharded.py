@@ -1,0 +1,69 @@
+"""Observation-sharded multi-GPU reduction.
+
+Every rank runs the fused pass on its own contiguous block of observations; the only
+communication is ONE all-reduce (RCCL over xGMI when the backend is "nccl", gloo on CPU in
+tests) of a zero-padded ``world x 8`` table in which each rank fills its own row with
+``[n, sum loo_i, M2 about its own mean, sum lppd_i, #k>good_k, #non-finite k, min diag, slow]``.
+Summing the table is an all-gather of the per-rank moments; they are then merged with the
+pairwise update of Chan, Golub & LeVeque (1983), which has no cancellation, so ``se`` and
+``p_loo_se`` equal the single-device ``np.var`` result to rounding (loo.py:327,340).
+"""
+
+import numpy as np
+
+from ._capi import AGG_COUNT, AGG_M2_LOO, AGG_MIN_DIAG, AGG_N, AGG_N_HIGH, AGG_N_NONFINITE, AGG_N_SLOW, AGG_SUM_LOO, AGG_SUM_LPPD
+
+
+def shard_bounds(n_obs, world_size, rank):
+    """Contiguous block ``[lo, hi)`` of observations owned by ``rank`` (sizes differ by <= 1)."""
+    base, rem = divmod(int(n_obs), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def merge_moment_rows(table):
+    """Combine per-rank aggregate rows (``world x AGG_COUNT``) into one aggregate vector."""
+    table = np.asarray(table, dtype=np.float64).reshape(-1, AGG_COUNT)
+    out = np.zeros(AGG_COUNT)
+    out[AGG_MIN_DIAG] = np.inf
+    n, mean, m2 = 0.0, 0.0, 0.0
+    for row in table:
+        nb = row[AGG_N]
+        if nb == 0:
+            continue
+        mb = row[AGG_SUM_LOO] / nb
+        if n == 0:
+            n, mean, m2 = nb, mb, row[AGG_M2_LOO]
+        else:
+            delta = mb - mean
+            tot = n + nb
+            m2 = m2 + row[AGG_M2_LOO] + delta * delta * n * nb / tot
+            mean = mean + delta * nb / tot
+            n = tot
+        out[AGG_SUM_LOO] += row[AGG_SUM_LOO]
+        out[AGG_SUM_LPPD] += row[AGG_SUM_LPPD]
+        out[AGG_N_HIGH] += row[AGG_N_HIGH]
+        out[AGG_N_NONFINITE] += row[AGG_N_NONFINITE]
+        out[AGG_N_SLOW] += row[AGG_N_SLOW]
+        out[AGG_MIN_DIAG] = min(out[AGG_MIN_DIAG], row[AGG_MIN_DIAG])
+    out[AGG_N] = n
+    out[AGG_M2_LOO] = m2
+    return out
+
+
+def all_reduce_aggregates(agg, group=None):
+    """``agg``: this rank's aggregate vector (CUDA tensor, CPU tensor or ndarray).
+    Returns the merged aggregate vector as a NumPy array, identical on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        a = agg.detach().cpu().numpy() if hasattr(agg, "detach") else np.asarray(agg)
+        return merge_moment_rows(a[None, :])
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    t = agg if hasattr(agg, "detach") else torch.as_tensor(np.asarray(agg), dtype=torch.float64)
+    table = torch.zeros((world, AGG_COUNT), dtype=torch.float64, device=t.device)
+    table[rank] = t.to(torch.float64)
+    dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)  # the single collective
+    return merge_moment_rows(table.cpu().numpy())
