@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Benchmark of the PSIS-LOO hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--obs N_PER_GPU] [--draws S]
+
+A "step" is one fused pass (``pla_psis_loo``: smoothing + loo_i + lppd_i + reductions, plus the
+single all-reduce when N > 1) over one device-resident synthetic log-likelihood matrix.  The
+default workload is BASELINE.json config C3 -- fp64, S=4000 draws x 1,000,000 observations per
+GPU (32 GB), reff=1 -- the configuration the north-star target is quoted on.  Observations are
+sharded over ranks (weak scaling: every GPU holds 1e6 rows); ``value`` is whole-job obs/s.
+
+One JSON line is printed by rank 0; it also carries
+  roofline      algorithmic bytes (8*S + 24 per observation) / mean kernel time, against 8 TB/s
+  cpu_baseline  the NumPy oracle (the reference's per-observation loop restated) on a bounded
+                sample of the same matrix, one core; the same sample is the parity check.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--obs", type=int, default=1_000_000, help="observations per GPU")
+    ap.add_argument("--draws", type=int, default=4000)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0003)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from pyloo_amd.base import tail_count_for
+    from pyloo_amd.engine import get_engine
+    from pyloo_amd.sharded import all_reduce_aggregates
+
+    eng = get_engine(local_rank)
+    S, n_local = args.draws, args.obs
+    tdt = torch.float64 if args.dtype == "f64" else torch.float32
+    esz = 8 if args.dtype == "f64" else 4
+    ll = torch.empty((n_local, S), dtype=tdt, device=dev)
+    eng.fill_synthetic(ll, seed=args.seed, row0=rank * n_local, k_lo=0.05, k_hi=0.60)
+    torch.cuda.synchronize()
+
+    reff = 1.0
+    M = tail_count_for(S, reff)
+    good_k = min(1 - 1 / np.log10(S), 0.7)
+
+    def step():
+        res = eng.psis_loo(ll, M, "psis", 1.0, good_k, pointwise=False, aggregate=True)
+        if world > 1:
+            return all_reduce_aggregates(res["agg"])  # the single collective (+ D2H of 8*world doubles)
+        return res["agg"]
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        agg = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    agg = agg.cpu().numpy() if hasattr(agg, "cpu") else np.asarray(agg)
+
+    # ---- roofline of the dominant kernel: hipEvents on the launch stream, outside the timed loop
+    eng.set_timing(True)
+    n_prof = max(3, min(args.steps, 10))
+    for _ in range(n_prof):
+        eng.psis_loo(ll, M, "psis", 1.0, good_k, pointwise=False, aggregate=True)
+    torch.cuda.synchronize()
+    k_ms, k_n = eng.kernel_ms()
+    eng.set_timing(False)
+    kernel_ms = k_ms / max(k_n, 1)
+    alg_bytes = n_local * (S * esz + 24.0)
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    out = {
+        "metric": "psis_loo_observations_per_second",
+        "value": world * n_local * args.steps / elapsed,
+        "unit": "obs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {
+            "workload": f"C3: synthetic {args.dtype} log_lik S={S} draws x N={n_local} observations per GPU, "
+                        f"PSIS-LOO reff=1 (M={M}), device-resident, obs-sharded",
+            "obs_per_gpu": n_local,
+            "draws": S,
+            "seed": hex(args.seed),
+            "elpd_loo": float(agg[1]),
+            "n_high_k": int(agg[4]),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel_ms": kernel_ms,
+            "algorithmic_bytes_per_launch": alg_bytes,
+        },
+    }
+
+    if not args.no_cpu:
+        # ---- CPU baseline + parity on a bounded sample of the same matrix (rank 0 only) -------
+        from oracle import psis_oracle as orc
+
+        chunk = 512
+        done, t_cpu = 0, 0.0
+        worst = {"khat": 0.0, "loo_i": 0.0, "lppd_i": 0.0}
+        full = eng.psis_loo(ll[: min(n_local, 65536)], M, "psis", 1.0, good_k)
+        torch.cuda.synchronize()
+        gk, gl, gp = (full[k].cpu().numpy() for k in ("diag", "loo_i", "lppd_i"))
+        while t_cpu < args.cpu_seconds and done + chunk <= min(n_local, 65536):
+            rows = ll[done:done + chunk].cpu().numpy().astype(np.float64)
+            c0 = time.perf_counter()
+            ref = orc.loo_pointwise(rows, reff)
+            t_cpu += time.perf_counter() - c0
+            sl = slice(done, done + chunk)
+            for key, got, want in (("khat", gk[sl], ref["diag"]), ("loo_i", gl[sl], ref["loo_i"]), ("lppd_i", gp[sl], ref["lppd_i"])):
+                err = np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-2))
+                worst[key] = max(worst[key], float(err))
+            done += chunk
+        out["cpu_baseline"] = {
+            "value": done / t_cpu if t_cpu > 0 else None,
+            "unit": "obs/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": f"first {done} observations of rank 0's matrix, NumPy oracle (per-observation loop "
+                      f"restating pyloo utils.py:171-175 + psis.py:114-160 + loo.py:289-337), {t_cpu:.1f} s",
+        }
+        out["parity"] = {"rows": done, "max_rel_err": worst, "tolerance": 1e-6}
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,6 +45,14 @@ def load_library():
             f"{LIB_PATH} is missing: the HIP engine has not been built "
             "(run `python -m pyloo_amd.build`).  pyloo_amd has no CPU fallback."
         )
+    # PyTorch-ROCm wheels bundle their own HIP runtime (same SONAME libamdhip64.so.7).  Two HIP
+    # runtimes in one process cannot both own the GPU, so torch must be loaded FIRST: our
+    # library's NEEDED entry then binds to the runtime torch already mapped, and torch tensors,
+    # streams and this engine share one HIP context.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is optional for pure NumPy callers
+        pass
     lib = C.CDLL(LIB_PATH)
     i64, dbl, vp, ci = C.c_int64, C.c_double, C.c_void_p, C.c_int
     lib.pla_abi_version.restype = ci

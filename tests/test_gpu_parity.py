@@ -35,6 +35,17 @@ def close(a, b, rtol=RTOL, atol=ATOL, what=""):
     np.testing.assert_allclose(a[ok], b[ok], rtol=rtol, atol=atol, err_msg=what)
 
 
+def has_tail_ties(ll_row, M):
+    """True when two draws of the PSIS tail share the same log ratio."""
+    x = -ll_row.astype(np.float64)
+    if not np.all(np.isfinite(x)):
+        return False
+    x = x - x.max()
+    cut = max(np.sort(x)[-M - 1], orc.LOG_TINY)
+    tail = x[x > cut]
+    return tail.size != np.unique(tail).size
+
+
 @pytest.mark.parametrize("case", [c[0] for c in cases.CASES])
 def test_golden_loo_pass(eng, case):
     g = load_golden(case)
@@ -54,11 +65,20 @@ def test_golden_weights(eng, case):
     lw, k = eng.importance_weights(-ll, M, "psis")
     assert lw.dtype == ll.dtype and k.dtype == np.float64
     close(k, g["khat"], what="khat")
+    want = g["lw"]
+    tied = [i for i in range(ll.shape[0]) if has_tail_ties(ll[i], M)]
+    if tied:
+        # Equal log ratios inside the tail: the reference hands the GPD quantiles to tied draws in
+        # the order of NumPy's unstable argsort (psis.py:146); the engine uses draw order.  The
+        # multiset of weights is identical, only which tied draw gets which quantile can differ.
+        lw, want = lw.copy(), want.copy()
+        for i in tied:
+            lw[i], want[i] = np.sort(lw[i]), np.sort(want[i])
     if ll.dtype == np.float32:
         # parity target for f32 input is the reference on the f64-upcast data, rounded to f32
-        close(lw, g["lw"].astype(np.float32), rtol=2e-7, atol=1e-7, what="lw")
+        close(lw, want.astype(np.float32), rtol=2e-7, atol=1e-7, what="lw")
     else:
-        close(lw, g["lw"], what="lw")
+        close(lw, want, what="lw")
     ok = ~np.isnan(lw).any(axis=1)
     np.testing.assert_allclose(np.exp(lw[ok].astype(np.float64)).sum(axis=1), 1.0, rtol=1e-5 if ll.dtype == np.float32 else 1e-12)
 
