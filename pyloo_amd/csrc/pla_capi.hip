@@ -49,6 +49,8 @@ struct pla_engine {
   size_t d_lw_bytes = 0;
   double* d_pw = nullptr;  // 3 * n doubles + agg
   size_t d_pw_elems = 0;
+  void* d_slow = nullptr;  // [n] row list of the fast path
+  size_t d_slow_bytes = 0;
   // timing of the main kernel
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -167,6 +169,7 @@ int pla_engine_destroy(pla_engine* e) {
   if (e->d_in) (void)hipFree(e->d_in);
   if (e->d_lw) (void)hipFree(e->d_lw);
   if (e->d_pw) (void)hipFree(e->d_pw);
+  if (e->d_slow) (void)hipFree(e->d_slow);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   delete e;
@@ -208,7 +211,7 @@ int pla_reduce_pointwise(pla_engine* eng, const double* diag, const double* loo_
   PLA_HIP(hipSetDevice(eng->device));
   hipStream_t s = (hipStream_t)stream;
   if (mem_space == PLA_DEVICE) {
-    pla::ReduceParams rp{diag, loo_i, lppd_i, n_obs, good_k, agg};
+    pla::ReduceParams rp{diag, loo_i, lppd_i, n_obs, good_k, agg, nullptr};
     PLA_HIP(pla::launch_reduce(rp, s));
     return PLA_OK;
   }
@@ -223,7 +226,7 @@ int pla_reduce_pointwise(pla_engine* eng, const double* diag, const double* loo_
   if (loo_i) { dl = d + n_obs; PLA_HIP(hipMemcpyAsync(dl, loo_i, n_obs * sizeof(double), hipMemcpyHostToDevice, s)); }
   if (lppd_i) { dp = d + 2 * n_obs; PLA_HIP(hipMemcpyAsync(dp, lppd_i, n_obs * sizeof(double), hipMemcpyHostToDevice, s)); }
   double* dagg = d + 3 * n_obs;
-  pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, dagg};
+  pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, dagg, nullptr};
   PLA_HIP(pla::launch_reduce(rp, s));
   PLA_HIP(hipMemcpyAsync(agg, dagg, PLA_AGG_COUNT * sizeof(double), hipMemcpyDeviceToHost, s));
   PLA_HIP(hipStreamSynchronize(s));
@@ -247,6 +250,11 @@ int pla_psis_loo(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int6
   p.tail_cap = pow2_at_least(p.tail_count);
   p.scale_value = scale_value;
   p.counters = eng->counters;
+  if (n_obs > 0) {
+    rc = grow(&eng->d_slow, &eng->d_slow_bytes, (size_t)n_obs * sizeof(unsigned));
+    if (rc) return rc;
+    p.slow_list = (unsigned*)eng->d_slow;
+  }
 
   if (mem_space == PLA_DEVICE) {
     // agg needs the pointwise loo_i: use the caller's vectors, or the engine scratch
@@ -271,7 +279,7 @@ int pla_psis_loo(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int6
       PLA_HIP(pla::launch_rows(p, dtype, false, s));
     }
     if (agg) {
-      pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, agg};
+      pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, agg, eng->counters};
       PLA_HIP(pla::launch_reduce(rp, s));
     }
     return PLA_OK;
@@ -325,7 +333,7 @@ int pla_psis_loo(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int6
     if (lppd_i) PLA_HIP(hipMemcpyAsync(lppd_i, dp, n_obs * sizeof(double), hipMemcpyDeviceToHost, s));
   }
   if (agg) {
-    pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, dagg};
+    pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, dagg, nullptr};
     PLA_HIP(pla::launch_reduce(rp, s));
     PLA_HIP(hipMemcpyAsync(agg, dagg, PLA_AGG_COUNT * sizeof(double), hipMemcpyDeviceToHost, s));
   }

@@ -20,7 +20,8 @@ struct RowsParams {
   double* loo_i;        // [n_obs] or null (LOO mode)
   double* lppd_i;       // [n_obs] or null (LOO mode)
   void* lw_out;         // (n_obs, n_draws) contiguous, input dtype (LW mode)
-  unsigned long long* counters;  // [4] device counters (slow rows, ...), may be null
+  unsigned long long* counters;  // [4] device counters: [0] rows left to the general kernel
+  unsigned* slow_list;           // [n_obs] workspace for the fast path (may be null: general kernel only)
 };
 
 struct ReduceParams {
@@ -30,6 +31,7 @@ struct ReduceParams {
   int64_t n_obs;
   double good_k;
   double* agg;  // [PLA_AGG_COUNT]
+  const unsigned long long* counters;  // [0] -> PLA_AGG_N_SLOW (may be null)
 };
 
 // returns hipSuccess or the launch error; never synchronises

@@ -170,12 +170,14 @@ def test_device_tensors_match_host(eng):
     big[:, :4000] = t
     view = big[:, :4000]
     dev2 = eng.psis_loo(view, 190, "psis", 1.0, 0.7)
-    assert np.array_equal(dev2["loo_i"].cpu().numpy(), host["loo_i"])
+    close(dev2["loo_i"].cpu().numpy(), host["loo_i"], what="strided rows")
+    close(dev2["diag"].cpu().numpy(), host["diag"], what="strided rows k")
     # obs-fastest layout (ArviZ native): handled through element strides, same numbers
     tt = t.t().contiguous().t()
     assert tt.stride(1) != 1
-    dev3 = eng.psis_loo(tt, 190, "psis", 1.0, 0.7)
-    assert np.array_equal(dev3["loo_i"].cpu().numpy(), host["loo_i"])
+    dev3 = eng.psis_loo(tt, 190, "psis", 1.0, 0.7)  # general kernel (not S-contiguous)
+    close(dev3["loo_i"].cpu().numpy(), host["loo_i"], what="obs-fastest")
+    close(dev3["diag"].cpu().numpy(), host["diag"], what="obs-fastest k")
 
 
 def test_input_not_modified_and_errors(eng):
