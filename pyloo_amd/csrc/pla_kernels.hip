@@ -15,6 +15,7 @@
 
 #include "pla_fast.h"
 #include "pla_rows.h"
+#include "pla_wave.h"
 
 namespace pla {
 
@@ -166,10 +167,55 @@ static hipError_t launch_fast(const RowsParams& p, int gsz, hipStream_t stream) 
   return hipGetLastError();
 }
 
+static int wave_groups(int S, int vec, int gsz) {
+  int g = 0;
+  for (int lane = 0; lane < kWave; ++lane)
+    for (int i = 0; i < kWaveSlots; i += gsz) {
+      const int s = vec * (lane + kWave * (i / vec)) + (i % vec);
+      if (s < S) ++g;
+    }
+  return g;
+}
+
+static int debug_flag(const char* name) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
+}
+
+template <typename T, int VEC>
+static hipError_t launch_wave(const RowsParams& p, int gsz, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return e;
+  static const int dbg = debug_flag("PLA_DEBUG_SKIP");
+  FastParams f{gsz, p.slow_list, p.counters, dbg};
+  int64_t grid = p.n_obs;
+  if (grid > 2048 * 8) grid = 2048 * 8;
+  hipLaunchKernelGGL((wave_loo_kernel<T, VEC>), dim3((unsigned)grid), dim3(kWave), 0, stream, p, f);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  constexpr int BLOCK = 256;
+  int64_t g2 = p.n_obs < 1024 ? p.n_obs : 1024;
+  hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap),
+                     stream, p);
+  return hipGetLastError();
+}
+
 template <typename T, bool LW>
 static hipError_t launch_typed(const RowsParams& p, hipStream_t stream) {
   constexpr int BLOCK = 256;
   const bool unit = (p.stride_draw == 1);
+  if constexpr (!LW) {
+    static const int path = debug_flag("PLA_FORCE_PATH");  // 0 auto, 1 general, 2 block-fast, 3 wave
+    constexpr int WVEC = 16 / sizeof(T);
+    const bool waligned = ((uintptr_t)p.in % 16 == 0) && (p.stride_obs % WVEC == 0) && (p.n_draws % WVEC == 0);
+    if (path != 1 && path != 2 && unit && waligned && p.method == PLA_PSIS && p.slow_list && p.counters &&
+        p.n_draws <= kWave * kWaveSlots && p.n_draws >= 256 && p.tail_count <= kWaveMaxTail &&
+        smem_bytes(BLOCK, p.tail_cap) <= 64 * 1024 && p.n_obs <= 0xffffffffll) {
+      for (int gsz = kWaveSlots; gsz >= 1; gsz >>= 1)
+        if (wave_groups(p.n_draws, WVEC, gsz) >= p.tail_count + 1) return launch_wave<T, WVEC>(p, gsz, stream);
+    }
+    if (path == 1) return launch_one<T, BLOCK, 0, LW>(p, stream);
+  }
   if constexpr (!LW) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int EPT = 16;
