@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/pyloo_amd.h"
 #include "pla_kernels.h"
@@ -51,6 +52,9 @@ struct pla_engine {
   size_t d_pw_elems = 0;
   void* d_slow = nullptr;  // [n] row list of the fast path
   size_t d_slow_bytes = 0;
+  double* d_l1 = nullptr;  // log1p(-(j+0.5)/M), j < M, for the current tail count
+  size_t d_l1_bytes = 0;
+  int64_t l1_M = -1;
   // timing of the main kernel
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -91,6 +95,29 @@ int check_common(pla_engine* eng, const void* in, int dtype, int64_t n_obs, int6
       return fail(PLA_ERR_UNSUPPORTED, "tail_count %lld exceeds the LDS tail capacity %d", (long long)tail_count,
                   pla::max_tail_count());
   }
+  return PLA_OK;
+}
+
+// Row-independent tables of the fast path, computed with the host libm exactly as NumPy does:
+//   [0, M)      log1p(-(j + 0.5)/M)              psis.py:153 through log1p of psis.py:219/221
+//   [M, M+64)   1 - sqrt(m_est / (j + 0.5))      psis.py:186 for m_est = 30 + isqrt(M)
+int ensure_l1_table(pla_engine* e, int64_t M, hipStream_t s) {
+  if (e->l1_M == M && e->d_l1) return PLA_OK;
+  void* p = e->d_l1;
+  int rc = grow(&p, &e->d_l1_bytes, (size_t)(M + 64) * sizeof(double));
+  e->d_l1 = (double*)p;
+  if (rc) return rc;
+  std::vector<double> h((size_t)M + 64);
+  for (int64_t j = 0; j < M; ++j) h[(size_t)j] = std::log1p(-(((double)j + 0.5) / (double)M));
+  int64_t root = (int64_t)std::sqrt((double)M);
+  while (root * root > M) --root;
+  while ((root + 1) * (root + 1) <= M) ++root;
+  const double mest = (double)(30 + root);
+  for (int j = 0; j < 64; ++j) h[(size_t)M + j] = 1.0 - std::sqrt(mest / ((double)(j + 1) - 0.5));
+  hipError_t he = hipMemcpyAsync(e->d_l1, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, s);
+  if (he == hipSuccess) he = hipStreamSynchronize(s);  // h goes out of scope
+  if (he != hipSuccess) return fail(PLA_ERR_HIP, "table upload: %s", hipGetErrorString(he));
+  e->l1_M = M;
   return PLA_OK;
 }
 
@@ -170,6 +197,7 @@ int pla_engine_destroy(pla_engine* e) {
   if (e->d_lw) (void)hipFree(e->d_lw);
   if (e->d_pw) (void)hipFree(e->d_pw);
   if (e->d_slow) (void)hipFree(e->d_slow);
+  if (e->d_l1) (void)hipFree(e->d_l1);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   delete e;
@@ -254,6 +282,11 @@ int pla_psis_loo(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int6
     rc = grow(&eng->d_slow, &eng->d_slow_bytes, (size_t)n_obs * sizeof(unsigned));
     if (rc) return rc;
     p.slow_list = (unsigned*)eng->d_slow;
+    if (method == PLA_PSIS) {
+      rc = ensure_l1_table(eng, tail_count, s);
+      if (rc) return rc;
+      p.l1_table = eng->d_l1;
+    }
   }
 
   if (mem_space == PLA_DEVICE) {

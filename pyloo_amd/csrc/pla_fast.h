@@ -151,6 +151,11 @@ struct FastParams {
   unsigned* slow_list;            // [n_obs] rows for the general kernel
   unsigned long long* counters;   // [0] = number of rows in slow_list
   int debug_skip;                 // phase-ablation bits for profiling (0 in production)
+  double* dbg;                    // debug dump (null in production)
+  const double* l1_table;         // [M] log1p(-(j+0.5)/M), host-computed (wave kernel)
+  double log_S;                   // log(n_draws)
+  const double* b_grid;           // [64] 1 - sqrt(m_est/(j+0.5)) for m_est = mest_M (psis.py:186)
+  int mest_M;                     // 30 + isqrt(M)
 };
 
 template <int BLOCK>

@@ -22,6 +22,7 @@ struct RowsParams {
   void* lw_out;         // (n_obs, n_draws) contiguous, input dtype (LW mode)
   unsigned long long* counters;  // [4] device counters: [0] rows left to the general kernel
   unsigned* slow_list;           // [n_obs] workspace for the fast path (may be null: general kernel only)
+  const double* l1_table;        // [tail_count] log1p(-(j+0.5)/M), then [64] 1 - sqrt(m_est/(j+0.5)) (host-computed)
 };
 
 struct ReduceParams {

@@ -11,6 +11,8 @@
 //   6. log-sum-exp normaliser, loo_i and lppd_i                       (psis.py:158, loo.py:289-337)
 // The weight matrix is never materialised in LOO mode: for draws outside the tail
 // lw_s + ll_s == -max - LSE exactly in real arithmetic, so only the <= M tail terms need an exp.
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 #include "pla_fast.h"
@@ -152,7 +154,7 @@ static hipError_t launch_fast(const RowsParams& p, int gsz, hipStream_t stream) 
   hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   static const int dbg = getenv("PLA_DEBUG_SKIP") ? atoi(getenv("PLA_DEBUG_SKIP")) : 0;
-  FastParams f{gsz, p.slow_list, p.counters, dbg};
+  FastParams f{gsz, p.slow_list, p.counters, dbg, nullptr, nullptr, 0.0, nullptr, 0};
   int64_t grid = p.n_obs;
   if (grid > 256 * 32) grid = 256 * 32;
   hipLaunchKernelGGL((fast_loo_kernel<T, EPT, VEC>), dim3((unsigned)grid), dim3(kFastBlock), fast_smem_bytes(),
@@ -187,12 +189,23 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, hipStream_t stream) 
   hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   static const int dbg = debug_flag("PLA_DEBUG_SKIP");
-  FastParams f{gsz, p.slow_list, p.counters, dbg};
+  int root_ = (int)std::sqrt((double)p.tail_count); while (root_ * root_ > p.tail_count) --root_; while ((root_ + 1) * (root_ + 1) <= p.tail_count) ++root_;
+  const int mestM = 30 + root_;
+  FastParams f{gsz, p.slow_list, p.counters, dbg, nullptr, p.l1_table, std::log((double)p.n_draws), p.l1_table + p.tail_count, mestM};
+  if (dbg & 64) (void)hipMalloc((void**)&f.dbg, 256 * sizeof(double));
   int64_t grid = p.n_obs;
   if (grid > 2048 * 8) grid = 2048 * 8;
   hipLaunchKernelGGL((wave_loo_kernel<T, VEC>), dim3((unsigned)grid), dim3(kWave), 0, stream, p, f);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
+  if (f.dbg) {
+    double h[256];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h, f.dbg, sizeof(h), hipMemcpyDeviceToHost);
+    for (int i = 0; i < 30; ++i) fprintf(stderr, "DBG[%d] = %.17g\n", i, h[i]);
+    
+    (void)hipFree(f.dbg);
+  }
   constexpr int BLOCK = 256;
   int64_t g2 = p.n_obs < 1024 ? p.n_obs : 1024;
   hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap),
@@ -208,7 +221,7 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream) {
     static const int path = debug_flag("PLA_FORCE_PATH");  // 0 auto, 1 general, 2 block-fast, 3 wave
     constexpr int WVEC = 16 / sizeof(T);
     const bool waligned = ((uintptr_t)p.in % 16 == 0) && (p.stride_obs % WVEC == 0) && (p.n_draws % WVEC == 0);
-    if (path != 1 && path != 2 && unit && waligned && p.method == PLA_PSIS && p.slow_list && p.counters &&
+    if (path != 1 && path != 2 && unit && waligned && p.method == PLA_PSIS && p.slow_list && p.counters && p.l1_table &&
         p.n_draws <= kWave * kWaveSlots && p.n_draws >= 256 && p.tail_count <= kWaveMaxTail &&
         smem_bytes(BLOCK, p.tail_cap) <= 64 * 1024 && p.n_obs <= 0xffffffffll) {
       for (int gsz = kWaveSlots; gsz >= 1; gsz >>= 1)

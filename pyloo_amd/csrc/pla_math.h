@@ -1,0 +1,112 @@
+// Lean fp64 elementary functions for the wave kernel (gfx950).  They exist because the fast path is
+// VALU-issue bound: the stock device-library calls carry long constant pools and special-case
+// code that cost registers and instructions on every row.  Accuracy is ~1-2 ulp on the domains
+// stated below -- far inside the 1e-9 the parity tests hold the engine to.
+#pragma once
+
+#include "pla_device.h"
+
+namespace pla {
+
+// ---- range reduction x = k*ln2/256 + r shared by every exponential -----------------------------
+constexpr int kTabN = 256;
+constexpr double kC256 = 369.32993046757463;              // 256 / ln 2
+constexpr double kMagic = 6755399441055744.0;             // 1.5 * 2^52: round-to-nearest-int trick
+constexpr double kLn2Hi256 = 2.70760617331688990816e-03;  // 6.93147180369123816490e-01 / 256
+constexpr double kLn2Lo256 = 7.45396456746323320e-13;     // 1.90821492927058770002e-10 / 256
+constexpr double kLn2_256 = 2.70760617406228627432e-03;    // ln 2 / 256 in one piece (|k| < 2^18: error < 1e-13)
+
+struct Red256 {
+  int k;     // round(x * 256 / ln 2)
+  double r;  // x - k ln2/256, |r| <= 0.00136
+};
+__device__ __forceinline__ Red256 reduce256(double x) {
+  const double t = fma(x, kC256, kMagic);
+  Red256 o;
+  o.k = (int)(unsigned)(__double_as_longlong(t) & 0xffffffffll);  // low mantissa bits hold k
+  const double kf = t - kMagic;
+  const double r = fma(kf, -kLn2Hi256, x);
+  o.r = fma(kf, -kLn2Lo256, r);
+  return o;
+}
+__device__ __forceinline__ int key256(double x) {
+  const double t = fma(x, kC256, kMagic);
+  return (int)(unsigned)(__double_as_longlong(t) & 0xffffffffll);
+}
+__device__ __forceinline__ double scale_exp(double v, int es) {  // v * 2^(es >> 20); result must stay normal
+  long long b = __double_as_longlong(v);
+  b += (long long)es << 32;
+  return __longlong_as_double(b);
+}
+// e^x for x in [-700, 709] from a table with tab[2*j] = 2^(j/256) (entries 16 bytes apart)
+__device__ __forceinline__ double exp_tab(double x, const double* tab) {
+  const Red256 q = reduce256(x);
+  const double tj = tab[2 * (q.k & 255)];
+  const double r2 = q.r * q.r;
+  const double E = fma(fma(4.16666666666666666667e-02, r2, 0.5), r2, 1.0);
+  const double O = fma(1.66666666666666666667e-01, r2, 1.0);
+  return scale_exp(tj * fma(q.r, O, E), (q.k >> 8) << 20);
+}
+// e^x for any x <= 0 (and NaN -> caller's problem): clamps where e^x underflows anyway
+__device__ __forceinline__ double exp_neg(double x, const double* tab) { return exp_tab(fmax(x, -700.0), tab); }
+
+// e^z - 1.  |z| < 2^-5: Taylor to z^9 (no cancellation); otherwise e^z - 1 from the table (the
+// subtraction loses at most 5 bits there).  z > 709 -> +inf, z < -700 -> -1.  NaN -> NaN.
+__device__ __forceinline__ double expm1_tab(double z, const double* tab) {
+  const double zc = fmin(fmax(z, -700.0), 709.0);
+  double p = 2.75573192239858906526e-06;  // 1/9!
+  p = fma(p, zc, 2.48015873015873015873e-05);
+  p = fma(p, zc, 1.98412698412698412698e-04);
+  p = fma(p, zc, 1.38888888888888888889e-03);
+  p = fma(p, zc, 8.33333333333333333333e-03);
+  p = fma(p, zc, 4.16666666666666666667e-02);
+  p = fma(p, zc, 1.66666666666666666667e-01);
+  p = fma(p, zc, 0.5);
+  p = fma(p * zc, zc, zc);
+  const double big = exp_tab(zc, tab) - 1.0;
+  double res = (fabs(zc) < 0.03125) ? p : big;
+  if (z > 709.0) res = pinf();
+  if (z != z) res = z;
+  return res;
+}
+
+// 1/d and a/d to ~1 ulp without the full IEEE division sequence (d normal, no overflow games)
+__device__ __forceinline__ double recip_fast(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double div_fast(double a, double d) {
+  const double r = recip_fast(d);
+  const double q = a * r;
+  return fma(fma(-q, d, a), r, q);
+}
+
+// natural log.  Main path for positive normal x (fdlibm e_log.c kernel, <1 ulp); zero, negative,
+// NaN, inf and subnormal inputs are patched up afterwards so the IEEE results match log().
+__device__ __forceinline__ double log_fast(double x) {
+  const bool sub = (x < 2.2250738585072014e-308) && (x > 0.0);
+  const double xs = sub ? x * 18014398509481984.0 : x;  // 2^54
+  int e = __builtin_amdgcn_frexp_exp(xs);               // xs = m * 2^e, m in [0.5, 1)
+  double m = __builtin_amdgcn_frexp_mant(xs);
+  if (m < 0.70710678118654752440) { m += m; e -= 1; }
+  if (sub) e -= 54;
+  const double f = m - 1.0;
+  const double s = div_fast(f, 2.0 + f);
+  const double z = s * s;
+  const double w = z * z;
+  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)e;
+  double res = dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+  if (x == 0.0) res = -pinf();
+  if (x < 0.0) res = qnan();
+  if (x != x) res = x;
+  if (x == pinf()) res = x;
+  return res;
+}
+
+}  // namespace pla

@@ -2,25 +2,36 @@
 //
 // One 64-lane wavefront owns one observation: the row of S draws sits in its registers
 // (64 slots per lane, loaded once with 16-byte loads), and every later step is done by that
-// wave alone with cross-lane shuffles and a private LDS scratch -- there is NO workgroup
+// wave alone with DPP cross-lane reductions and a private LDS scratch -- there is NO workgroup
 // barrier anywhere, so the 8 waves resident on a CU run their phases (HBM load, exp sweep,
 // selection, GPD fit) completely decoupled and cover each other's latencies.
 //
-//   stats     max / min / non-finite count / min over groups of the group maxima (threshold t1:
+//   stats     max / min / non-finite test / min over groups of the group maxima (threshold t1:
 //             at least #groups >= M+1 draws lie at or above it)
-//   sweep     for every draw: e^x and e^(ll - max ll) from ONE range reduction with a 32-entry
-//             2^(j/32) table and a degree-6 polynomial (the exponents are x and -x-R);
-//             draws >= t1 are counted in a 1024-bin linear LDS histogram
-//   select    suffix scan -> boundary bin of rank M; candidates at/above it are scattered to
-//             LDS grouped by bin and ranked exactly inside their bin
+//   sweep     for every draw ONE range reduction x = k*ln2/256 + r gives both e^x and
+//             e^(ll - max ll) = e^(-x-R): a 256-entry LDS table of {2^(j/256), 2^(-j/256) e^-R},
+//             a degree-4 even/odd polynomial and an integer add to the exponent field.
+//             The integer k doubles as the histogram key: draws with k >= k(t1) are counted in
+//             up to 1024 linear bins of width 2^sh * ln2/256.
+//   select    suffix scan -> boundary bin of rank M; draws at/above it are scattered to LDS
+//             grouped by bin and ranked exactly inside their bin
 //   fit       Zhang-Stephens GPD fit, one lane per grid point b_j, log(prod) instead of sum(log1p)
 //   smooth    GPD quantiles, sums of the smoothed weights; loo_i / lppd_i from the sums
+//
+// Slots beyond S are padded so that no per-slot predicate is needed: first with a copy of the
+// lane's own first draws (harmless for max/min), then with ll = -min raw (x = -R, the smallest
+// x of the row), whose exactly known contribution is subtracted from the two sums.
 //
 // Rows the shortcuts cannot reproduce exactly as the reference computes them are appended to a
 // list and recomputed by the general kernel (pla_rows.h).
 #pragma once
 
 #include "pla_fast.h"
+#include "pla_math.h"
+
+#ifndef PLA_ROW_INLINE
+#define PLA_ROW_INLINE __attribute__((noinline))
+#endif
 
 namespace pla {
 
@@ -28,24 +39,56 @@ constexpr int kWaveSlots = 64;   // register slots per lane -> S <= 4096
 constexpr int kWaveBins = 1024;
 constexpr int kWaveCap = 320;    // candidates kept in LDS; needs M + boundary-bin extras
 constexpr int kWaveMaxTail = 250;
+constexpr double kWaveMaxRange = 690.0;  // nats: e^x, e^-x and their sums over 4096 draws stay finite and normal
 
-__device__ __forceinline__ double uniform_d(double v) {  // value is wave-uniform: move to SGPRs
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll));
-  const int hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+// ---- wave-wide reductions with DPP (result in SGPRs) -----------------------------------------
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_mov(double v, double ident) {
+  const long long b = __double_as_longlong(v), o = __double_as_longlong(ident);
+  const int lo = __builtin_amdgcn_update_dpp((int)(o & 0xffffffffll), (int)(b & 0xffffffffll), CTRL, ROWMASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(b >> 32), CTRL, ROWMASK, 0xF, false);
   return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
-template <RedOp OP>
-__device__ __forceinline__ double wave_all(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = red_apply<OP>(v, __shfl_xor(v, o));
-  return uniform_d(v);
+__device__ __forceinline__ double lane_value(double v, int lane) {  // wave-uniform result
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
-__device__ __forceinline__ int wave_bin(double x, double t1, double scale) {
-  const int b = (int)((x - t1) * scale);
-  return b < kWaveBins - 1 ? b : kWaveBins - 1;
+__device__ __forceinline__ double uniform_d(double v) { return lane_value(v, 0); }
+
+// max without the canonicalising self-max the compiler adds around fmax (NaNs are detected
+// separately with v_cmp_class); NEG folds the sign flip of the first operand into the instruction
+template <bool NEG>
+__device__ __forceinline__ double vmax_nc(double a, double b) {
+  double d;
+  if constexpr (NEG) asm("v_max_f64 %0, -%1, %2" : "=v"(d) : "v"(a), "v"(b));
+  else asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+template <bool NEG>
+__device__ __forceinline__ float vmax_nc(float a, float b) {
+  float d;
+  if constexpr (NEG) asm("v_max_f32 %0, -%1, %2" : "=v"(d) : "v"(a), "v"(b));
+  else asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+template <RedOp OP>
+__device__ __forceinline__ double wave_all(double v) {
+  const double id = (OP == R_SUM) ? 0.0 : ((OP == R_MAX) ? -pinf() : pinf());
+  v = red_apply<OP>(v, dpp_mov<0xB1, 0xF>(v, id));   // quad_perm [1,0,3,2]
+  v = red_apply<OP>(v, dpp_mov<0x4E, 0xF>(v, id));   // quad_perm [2,3,0,1]
+  v = red_apply<OP>(v, dpp_mov<0x141, 0xF>(v, id));  // row_half_mirror
+  v = red_apply<OP>(v, dpp_mov<0x140, 0xF>(v, id));  // row_mirror: every lane has its row's result
+  v = red_apply<OP>(v, dpp_mov<0x142, 0xA>(v, id));  // row_bcast:15 into rows 1 and 3
+  v = red_apply<OP>(v, dpp_mov<0x143, 0xC>(v, id));  // row_bcast:31 into rows 2 and 3
+  return lane_value(v, 63);
 }
 
 struct WaveSmem {
@@ -53,289 +96,412 @@ struct WaveSmem {
   unsigned start[kWaveBins];
   double sa[kWaveCap];
   double sb[kWaveCap];
-  double tab[64];  // [0,32): 2^(j/32)   [32,64): 2^(-j/32) * cR
+  double tab[2 * kTabN];  // {2^(j/256), 2^(-j/256)} interleaved: one 16-byte read serves both exponentials
 };
 
+// phase ablation for profiling (tools/ablate.sh); compiled out of the production kernel
+#ifndef PLA_WAVE_ABLATE
+#define PLA_WAVE_ABLATE 0
+#endif
+
+__device__ __forceinline__ double add_hi(double v, int d) {  // v * 2^(d >> 20) for normal v and result
+  return __hiloint2double(__double2hiint(v) + d, __double2loint(v));
+}
+
 template <typename T, int VEC>
-__global__ __launch_bounds__(kWave, 2) void wave_loo_kernel(RowsParams P, FastParams F) {
+__device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParams& F, WaveSmem& sm, const int64_t r,
+                                            const T* rp) {
   constexpr int EPT = kWaveSlots;
-  __shared__ WaveSmem sm;
+  constexpr int NQ = EPT / VEC;
   const int lane = threadIdx.x;
-  const int S = P.n_draws;
-  const int M = P.tail_count;
+  // parameters arrive by reference (memory): read each once into scalar registers
+  const int S = __builtin_amdgcn_readfirstlane(P.n_draws);
+  const int M = __builtin_amdgcn_readfirstlane(P.tail_count);
+  const int gsz = __builtin_amdgcn_readfirstlane(F.gsz);
+#if PLA_WAVE_ABLATE
+  const int dbgs = __builtin_amdgcn_readfirstlane(F.debug_skip);
+#else
+  constexpr int dbgs = 0;
+#endif
+  const double* l1tab = F.l1_table;
+  const double* bgrid = F.b_grid;
+  const int mestM = __builtin_amdgcn_readfirstlane(F.mest_M);
+  const double logS = uniform_d(F.log_S);
   const double INF = pinf();
-  typedef T VT __attribute__((ext_vector_type(VEC)));
+  const int nvec = S / VEC;                       // 16-byte vectors per row (S % VEC == 0)
+  const int qfull = nvec / kWave;                 // q < qfull: every lane valid
+  const int qrem = nvec - qfull * kWave;          // q == qfull: lanes < qrem valid
+  typedef int v4i __attribute__((ext_vector_type(4)));
 
-  // 2^(j/32), j = 0..31 (exact to rounding; exp2 is correctly rounded enough at these points)
-  if (lane < 32) sm.tab[lane] = exp2((double)lane * 0.03125);
-  __syncthreads();
-
-  for (int64_t r = blockIdx.x; r < P.n_obs; r += gridDim.x) {
-    const T* rp = reinterpret_cast<const T*>(P.in) + r * P.stride_obs;
-    // ---- load: slot i holds draw  VEC*(lane + 64*(i/VEC)) + i%VEC ------------------------------
-    T v[EPT];
+  // ---- load: slot q*VEC+e holds draw VEC*(lane + 64 q) + e.  Buffer loads with the row as the
+  // bounds-checked range: one VGPR offset (lane*16), scalar per-q offsets, zeros past the row.
+  T v[EPT];
+  {
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(rp), 0, S * (int)sizeof(T), 0x00020000);
 #pragma unroll
-    for (int q = 0; q < EPT / VEC; ++q) {
-      const int s0 = VEC * (lane + kWave * q);
-      if (s0 < S) {
-        const VT t = __builtin_nontemporal_load(reinterpret_cast<const VT*>(rp + s0));
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) v[q * VEC + e] = t[e];
+    for (int q = 0; q < NQ; ++q) {
+      const v4i t = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, q * (kWave * 16), 2 /* nt */);
+      if constexpr (VEC == 2) {
+        v[2 * q] = (T)__hiloint2double(t[1], t[0]);
+        v[2 * q + 1] = (T)__hiloint2double(t[3], t[2]);
       } else {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) v[q * VEC + e] = T(0);
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = (T)__int_as_float(t[e]);
       }
     }
-    // ---- 1. row statistics ----------------------------------------------------------------------
-    double mx = -INF, mn = INF, gmin = INF, nbad = 0.0;
+    // slots past the row: copy this lane's first vector (harmless for max / min / threshold)
+#pragma unroll
+    for (int q = 1; q < NQ; ++q) {
+      if (q >= qfull) {  // wave-uniform
+        const bool ok = (q == qfull) && (lane < qrem);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[q * VEC + e] = ok ? v[q * VEC + e] : v[e];
+      }
+    }
+  }
+  asm volatile("; MARK stats_begin");
+  // ---- 1. row statistics, in the input precision (exact; duplicates of valid draws are harmless) ---
+  // raw = -ll:  max raw = max(-v),  min raw = -max(v).  chk = sum v*0 is NaN iff some v is NaN/+-inf.
+  double mx, mn, gmin;
+  bool bad;
+  {
+    const T ninf = (T)(-INF);
+    T gcur = ninf, vmx = ninf, gmx = ninf, gmn = (T)INF, chk = T(0);
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      gcur = vmax_nc<true>(v[i], gcur);
+      vmx = vmax_nc<false>(v[i], vmx);
+      chk = fma_t(v[i], T(0), chk);
+      if (((i + 1) & (gsz - 1)) == 0) {
+        // a group made only of pads repeats this lane's first draws: it can only lower gmin
+        gmn = -vmax_nc<true>(gcur, -gmn);  // min(gmn, gcur)
+        gmx = vmax_nc<false>(gcur, gmx);
+        gcur = ninf;
+      }
+    }
+    mx = (double)gmx;
+    mn = -(double)vmx;
+    gmin = (double)gmn;
+    bad = chk != chk;
+  }
+  asm volatile("; MARK stats_end");
+  const double m = wave_all<R_MAX>(mx);
+  mn = wave_all<R_MIN>(mn);
+  gmin = wave_all<R_MIN>(gmin);
+  const bool anybad = __ballot(bad) != 0ull;
+  const double R = m - mn;
+  const double t1 = gmin - m;
+  bool slow = anybad || !(R < kWaveMaxRange) || !(t1 < 0.0);
+  const int k1 = key256(t1);                 // histogram origin
+  const int kpad = key256(-R);               // key of the pad value (smallest x of the row)
+  if (kpad >= k1) slow = true;               // pads would be counted as candidates
+  double khat = INF, loo = 0.0, lppd = 0.0;
+  if (!slow) {
+  asm volatile("; MARK setup_begin");
+    // bins: (k - k1) >> sh  in [0, 1023] for k in [k1, 0]
+    const int span = -k1;
+    const int sh = (span >> 10) ? (32 - __builtin_clz((unsigned)(span >> 10))) : 0;
+    __syncthreads();  // previous row is done with the histogram
     {
-      double gcur = -INF;
-      bool ghas = false;
+      const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-      for (int i = 0; i < EPT; ++i) {
-        const int s = VEC * (lane + kWave * (i / VEC)) + (i % VEC);
-        if (s < S) {
-          const double raw = -(double)v[i];
-          mx = fmax(mx, raw);
-          mn = fmin(mn, raw);
-          if (!(fabs(raw) <= 1.7976931348623157e308)) nbad += 1.0;
-          gcur = fmax(gcur, raw);
-          ghas = true;
-        }
-        if (((i + 1) & (F.gsz - 1)) == 0) {
-          if (ghas) gmin = fmin(gmin, gcur);
-          gcur = -INF;
-          ghas = false;
-        }
+      for (int i = 0; i < kWaveBins / (4 * kWave); ++i) *reinterpret_cast<uint4*>(&sm.hist[4 * (lane + kWave * i)]) = z4;
+    }
+    // pads: rewrite invalid vectors to ll = -mn  (raw = mn, x = -R)
+    const T padv = (T)(-mn);
+#pragma unroll
+    for (int q = 1; q < NQ; ++q) {
+      if (q >= qfull) {  // uniform
+        const bool ok = (q == qfull && lane < qrem);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[q * VEC + e] = ok ? v[q * VEC + e] : padv;
       }
     }
-    const double m = wave_all<R_MAX>(mx);
-    mn = wave_all<R_MIN>(mn);
-    gmin = wave_all<R_MIN>(gmin);
-    nbad = wave_all<R_SUM>(nbad);
-    const double R = m - mn;
-    const double t1 = gmin - m;
-    bool slow = (nbad != 0.0) || !(R < kFastMaxRange) || !(t1 < 0.0);
-    double khat = INF, loo = 0.0, lppd = 0.0;
-    if (!slow) {
-      const double scale = (double)kWaveBins / (-t1);
-      // per-row pieces of the second exponential: e^-R = cR * 2^-kR
-      double cR;
-      int kR;
+    __syncthreads();
+  asm volatile("; MARK sweep_begin");
+    // ---- 2. sweep: e^x and e^-x of every draw from one range reduction + histogram of candidates ----
+    // (e^(ll - max ll) = e^-R * e^-x; the row constant e^-R is applied to the sum, in log space)
+    double s1 = 0.0, s2 = 0.0;
+    const double* tab = sm.tab;
+    double magic = kMagic;
+    unsigned one = 1u;
+    asm volatile("" : "+v"(magic), "+v"(one));  // keep both resident instead of re-materialising per draw
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const double x = (-(double)v[i]) - m;  // psis.py:134
+      const double t = fma(x, kC256, magic);
+      const int k = __double2loint(t);        // round(x * 256/ln2): low mantissa bits of t
+      if (!(dbgs & 1)) {
+        const double rr = fma(t - magic, -kLn2_256, x);
+        const double2 tt = *reinterpret_cast<const double2*>(tab + 2 * (k & 255));
+        const double r2 = rr * rr;
+        const double E = fma(fma(4.16666666666666666667e-02, r2, 0.5), r2, 1.0);
+        const double O = fma(1.66666666666666666667e-01, r2, 1.0);
+        const int es = (k << 12) & 0xfff00000;  // (k >> 8) << 20
+        s1 += add_hi(tt.x * fma(rr, O, E), es);
+        s2 += add_hi(tt.y * fma(-rr, O, E), -es);
+      }
+      if (k >= k1 && !(dbgs & 2)) atomicAdd(&sm.hist[(k - k1) >> sh], one);
+      // pin the running sums here: otherwise the whole accumulation chain is sunk below the 64
+      // histogram branches and its inputs (table entries, reduced arguments) spill
+      asm volatile("" : "+v"(s1), "+v"(s2));
+    }
+  asm volatile("; MARK sweep_end");
+    {  // remove the pads' contribution (same code path, so it cancels to rounding)
+      const double x = -R;
+      const double t = fma(x, kC256, magic);
+      const int k = __double2loint(t);
+      const double rr = fma(t - magic, -kLn2_256, x);
+      const double2 tt = *reinterpret_cast<const double2*>(tab + 2 * (k & 255));
+      const double r2 = rr * rr;
+      const double E = fma(fma(4.16666666666666666667e-02, r2, 0.5), r2, 1.0);
+      const double O = fma(1.66666666666666666667e-01, r2, 1.0);
+      const int es = (k << 12) & 0xfff00000;
+      const double npad = (double)((NQ - qfull) * VEC - ((lane < qrem) ? VEC : 0));  // padded slots of this lane
+      if (!(dbgs & 1)) {
+        s1 -= npad * add_hi(tt.x * fma(rr, O, E), es);
+        s2 -= npad * add_hi(tt.y * fma(-rr, O, E), -es);
+      }
+    }
+    __syncthreads();
+    if (dbgs & 4) {
+      loo = s1;
+      lppd = s2;
+    } else {
+  asm volatile("; MARK scan_begin");
+      // ---- 3. suffix scan (16 bins per lane): start[b] = #draws in bins above b ---------------
+      int bstar = 0, C1 = 0;
       {
-        const double kf = rint(R * 1.4426950408889634);
-        double rr = fma(kf, -6.93147180369123816490e-01, R);
-        rr = fma(kf, -1.90821492927058770002e-10, rr);
-        cR = exp(-rr);
-        kR = (int)kf;
-      }
-      __syncthreads();  // previous row is done with the tables / histogram
-      if (lane < 32) sm.tab[32 + lane] = cR / sm.tab[lane];
+        unsigned c[16];
+        unsigned tot = 0;
 #pragma unroll
-      for (int i = 0; i < kWaveBins / kWave; ++i) sm.hist[lane + kWave * i] = 0;
-      __syncthreads();
-      // ---- 2. sweep: both exponentials of every draw + histogram of the candidates -----------
-      double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-      for (int i = 0; i < EPT; ++i) {
-        const int s = VEC * (lane + kWave * (i / VEC)) + (i % VEC);
-        if (s < S) {
-          const double x = (-(double)v[i]) - m;  // psis.py:134
-          if (!(F.debug_skip & 1)) {
-            const double kf = rint(x * 46.16624130844683);  // 32 / ln 2
-            double rr = fma(kf, -2.16608493865351192653e-02, x);   // ln2_hi / 32
-            rr = fma(kf, -5.96317165397058656257e-12, rr);          // ln2_lo / 32
-            const int k = (int)kf;
-            const int j = k & 31;
-            const int e = k >> 5;
-            const double tj = sm.tab[j], ij = sm.tab[32 + j];
-            const double r2 = rr * rr;
-            double E = fma(1.38888888888888888889e-03, r2, 4.16666666666666666667e-02);
-            E = fma(E, r2, 0.5);
-            E = fma(E, r2, 1.0);
-            double O = fma(8.33333333333333333333e-03, r2, 1.66666666666666666667e-01);
-            O = fma(O, r2, 1.0);
-            const double rO = rr * O;
-            s1 += ldexp(tj * (E + rO), e);
-            s2 += ldexp(ij * (E - rO), -e - kR);
-          }
-          if (x >= t1 && !(F.debug_skip & 2)) atomicAdd(&sm.hist[wave_bin(x, t1, scale)], 1u);
+        for (int i = 0; i < 4; ++i) {
+          const uint4 h = *reinterpret_cast<const uint4*>(&sm.hist[16 * lane + 4 * i]);
+          c[4 * i] = h.x; c[4 * i + 1] = h.y; c[4 * i + 2] = h.z; c[4 * i + 3] = h.w;
+          tot += h.x + h.y + h.z + h.w;
         }
+        unsigned suf = tot;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+          const unsigned t = (unsigned)__shfl_down((int)suf, o);
+          if (lane + o < kWave) suf += t;
+        }
+        unsigned a = suf - tot;  // draws in bins owned by higher lanes
+        int fb = -1, fc = 0;
+        unsigned st[16];
+#pragma unroll
+        for (int i = 15; i >= 0; --i) {
+          st[i] = a;
+          if ((unsigned)M >= a && (unsigned)M < a + c[i]) {
+            fb = 16 * lane + i;
+            fc = (int)(a + c[i]);
+          }
+          a += c[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          *reinterpret_cast<uint4*>(&sm.start[16 * lane + 4 * i]) = make_uint4(st[4 * i], st[4 * i + 1], st[4 * i + 2], st[4 * i + 3]);
+        const unsigned long long who = __ballot(fb >= 0);
+        const int src = __ffsll((long long)who) - 1;
+        bstar = __builtin_amdgcn_readlane(fb, src);
+        C1 = __builtin_amdgcn_readlane(fc, src);
       }
       __syncthreads();
-      if (F.debug_skip & 4) {
-        loo = s1;
-        lppd = s2;
+      if (C1 > kWaveCap) {
+        slow = true;
       } else {
-        // ---- 3. suffix scan (16 bins per lane): start[b] = #draws in bins above b ---------------
-        int bstar = 0, C1 = 0;
-        {
-          unsigned c[16];
-          unsigned tot = 0;
+  asm volatile("; MARK scatter_begin");
+        // ---- 4. candidates -> LDS grouped by bin (descending bins) -----------------------------
+        const int kstar = k1 + (bstar << sh);
+        // recompute x and its key from the row registers; the laundered copy of m keeps the compiler
+        // from carrying 64 live x values over from the sweep (they would spill)
+        double m2 = m;
+        asm volatile("" : "+s"(m2));
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            c[i] = sm.hist[16 * lane + i];
-            tot += c[i];
+        for (int i = 0; i < EPT; ++i) {
+          const double x = (-(double)v[i]) - m2;
+          const int k = __double2loint(fma(x, kC256, magic));
+          if (k >= kstar) {
+            const int b = (k - k1) >> sh;
+            const unsigned slot = sm.start[b] + (atomicSub(&sm.hist[b], 1u) - 1u);
+            sm.sa[slot] = x;
           }
-          unsigned suf = tot;
-#pragma unroll
-          for (int o = 1; o < kWave; o <<= 1) {
-            const unsigned t = (unsigned)__shfl_down((int)suf, o);
-            if (lane + o < kWave) suf += t;
-          }
-          unsigned a = suf - tot;  // draws in bins owned by higher lanes
-          int fb = -1, fc = 0;
-#pragma unroll
-          for (int i = 15; i >= 0; --i) {
-            sm.start[16 * lane + i] = a;
-            if (fb < 0 && (unsigned)M >= a && (unsigned)M < a + c[i]) {
-              fb = 16 * lane + i;
-              fc = (int)(a + c[i]);
-            }
-            a += c[i];
-          }
-          // exactly one lane found the boundary bin
-          const unsigned long long who = __ballot(fb >= 0);
-          const int src = __ffsll((long long)who) - 1;
-          bstar = __shfl(fb, src);
-          C1 = __shfl(fc, src);
         }
         __syncthreads();
-        if (C1 > kWaveCap) {
-          slow = true;
-        } else {
-          // ---- 4. candidates -> LDS grouped by bin (descending bins) -----------------------------
-#pragma unroll
-          for (int i = 0; i < EPT; ++i) {
-            const int s = VEC * (lane + kWave * (i / VEC)) + (i % VEC);
-            if (s < S) {
-              const double x = (-(double)v[i]) - m;
-              if (x >= t1) {
-                const int b = wave_bin(x, t1, scale);
-                if (b >= bstar) {
-                  const unsigned slot = sm.start[b] + (atomicSub(&sm.hist[b], 1u) - 1u);
-                  sm.sa[slot] = x;
-                }
-              }
-            }
+  asm volatile("; MARK rank_begin");
+        // ---- 5. exact descending rank inside each bin (ties: arbitrary, the sums do not care) --
+        for (int c = lane; c < C1; c += kWave) {
+          const double x = sm.sa[c];
+          const int b = (key256(x) - k1) >> sh;
+          const int lo = (int)sm.start[b];
+          const int hi = (b > 0) ? (int)sm.start[b - 1] : C1;
+          int cnt = 0;
+          for (int c2 = lo; c2 < hi; ++c2) {
+            const double x2 = sm.sa[c2];
+            cnt += (x2 > x || (x2 == x && c2 > c)) ? 1 : 0;
           }
-          __syncthreads();
-          // ---- 5. exact descending rank inside each bin (ties: arbitrary, the sums do not care) --
-          for (int c = lane; c < C1; c += kWave) {
-            const double x = sm.sa[c];
-            const int b = wave_bin(x, t1, scale);
-            const int lo = (int)sm.start[b];
-            const int hi = (b > 0) ? (int)sm.start[b - 1] : C1;
-            int cnt = 0;
-            for (int c2 = lo; c2 < hi; ++c2) {
-              const double x2 = sm.sa[c2];
-              cnt += (x2 > x || (x2 == x && c2 > c)) ? 1 : 0;
-            }
-            sm.sb[lo + cnt] = x;
-          }
-          __syncthreads();
-          // ---- cutoff (psis.py:135-141); R < 700: the log(DBL_MIN) floor cannot bind -------------
-          const double xcut = sm.sb[M];
-          int n = M;
-          while (n > 0 && sm.sb[n - 1] == xcut) --n;  // ties at the cutoff leave the tail
-          const double e_cut = exp(xcut);
-          double acc_w = 0.0, acc_r = 0.0, acc_e = 0.0;
-          bool smoothed = false;
-          if (n > 4 && !(F.debug_skip & 8)) {
-            __syncthreads();
-            for (int j = lane; j < n; j += kWave) sm.sa[j] = exp(sm.sb[n - 1 - j]) - e_cut;  // psis.py:147
-            __syncthreads();
-            const double* y = sm.sa;
-            // ---- 6. GPD fit (psis.py:163-208), lane j <-> grid point b_j -------------------------
-            const int mest = 30 + isqrt_i(n);
-            const double yq = y[((n + 2) >> 2) - 1];
-            const double yn = y[n - 1];
-            const bool act = lane < mest;
-            double b = 1.0 - sqrt((double)mest / ((double)(lane + 1) - 0.5));  // psis.py:186
-            b /= 3.0 * yq;                                                      // psis.py:187
-            b += 1.0 / yn;                                                      // psis.py:188
-            const double b_first = uniform_d(b);                        // lane 0: most negative
-            const double b_last = uniform_d(__shfl(b, mest - 1));
-            const double fbig = fma(-b_first, yn, 1.0), fsmall = fma(-b_last, yn, 1.0);
-            const bool wide = (fbig < 0x1p100) && (fsmall > 0x1p-100);
-            ProdAcc acc;
-            acc.init();
-            const double nb = -b;
-            int i = 0;
-            if (wide) {
-              for (; i + 8 <= n; i += 8) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc.mul(fma(nb, y[i + u], 1.0));
-                acc.renorm();
-              }
-              for (; i < n; ++i) acc.mul(fma(nb, y[i], 1.0));
-              acc.renorm();
-            } else {
-              for (; i < n; ++i) { acc.mul(fma(nb, y[i], 1.0)); acc.renorm(); }
-            }
-            const double kj = acc.log_value() / (double)n;                     // psis.py:190
-            double ls = (double)n * (log(-(b / kj)) - kj - 1.0);               // psis.py:191
-            const bool anynan = __ballot(act && (ls != ls)) != 0ull;
-            const double lmax = wave_all<R_MAX>(act ? ls : -INF);
-            double w = act ? exp(ls - lmax) : 0.0;                             // psis.py:192
-            const double se = wave_all<R_SUM>(w);
-            w = anynan ? qnan() : w / se;
-            const bool keep = act && (w >= 10.0 * kEps);                       // psis.py:194-197
-            const double sw = wave_all<R_SUM>(keep ? w : 0.0);
-            const double b_post = wave_all<R_SUM>(keep ? b * (w / sw) : 0.0);  // psis.py:198,201
-            double lp = 0.0;
-            for (int ii = lane; ii < n; ii += kWave) lp += log1p(-b_post * y[ii]);  // psis.py:203
-            const double k_post = wave_all<R_SUM>(lp) / (double)n;
-            const double sigma = -k_post / b_post;                             // psis.py:205
-            khat = ((double)n * k_post + 5.0) / ((double)n + 10.0);           // psis.py:206
-            if (isfinite(khat)) {
-              smoothed = true;
-              for (int j = lane; j < n; j += kWave) {
-                const double p = ((double)j + 0.5) / (double)n;                // psis.py:153
-                double q;
-                if (sigma <= 0.0) {
-                  q = qnan();                                                  // psis.py:214-215
-                } else {
-                  const double l1 = log1p(-p);
-                  q = (fabs(khat) < kEps) ? -l1 : expm1(-khat * l1) / khat;    // psis.py:218-221
-                  q *= sigma;
-                }
-                double wj = q + e_cut;   // exp(log(q + e_cut)), psis.py:155
-                if (wj > 1.0) wj = 1.0;  // psis.py:157
-                const double ej = y[j] + e_cut;
-                acc_w += wj;
-                acc_r += wj / ej;
-                acc_e += ej;
-              }
-            }
-          }
-          s1 = wave_all<R_SUM>(s1);
-          s2 = wave_all<R_SUM>(s2);
-          double total = s1;
-          if (smoothed) {
-            acc_w = wave_all<R_SUM>(acc_w);
-            acc_r = wave_all<R_SUM>(acc_r);
-            acc_e = wave_all<R_SUM>(acc_e);
-            total = (s1 - acc_e) + acc_w;
-          }
-          const double L = log(total);                                          // psis.py:158
-          const double A = (-m) - L;
-          loo = smoothed ? A + log((double)(S - n) + acc_r) : A + log((double)S);
-          lppd = log(s2) + ((-mn) - log((double)S));                          // loo.py:329-337
-          if ((!(total > 1e-280) || !isfinite(loo) || !isfinite(lppd)) && !F.debug_skip) slow = true;
+          sm.sb[lo + cnt] = x;
         }
+        __syncthreads();
+  asm volatile("; MARK cut_begin");
+        // ---- cutoff (psis.py:135-141); R < 690: the log(DBL_MIN) floor cannot bind -------------
+        const double xcut = sm.sb[M];
+        int n = M;
+        while (n > 0 && sm.sb[n - 1] == xcut) --n;  // ties at the cutoff leave the tail
+        const double e_cut = exp_tab(xcut, sm.tab);
+        double acc_t = 0.0, acc_r = 0.0;  // (sum w' - sum e) and sum w'/e over the tail
+        bool smoothed = false;
+        if (n > 4 && !(dbgs & 8)) {
+          __syncthreads();
+          // y ascending (psis.py:146-147), stored with the pair sums / products the fit loop eats
+          for (int j = lane; j < n; j += kWave) sm.sa[j] = exp_tab(sm.sb[n - 1 - j], sm.tab) - e_cut;
+          __syncthreads();
+          const double* y = sm.sa;
+          const double nn = (double)n;
+          // (1 - b y0)(1 - b y1) = 1 - b (y0 + y1) + b^2 y0 y1: pair sums / products once per row
+          for (int p2 = lane; 2 * p2 + 1 < n; p2 += kWave) {
+            const double2 yy = *reinterpret_cast<const double2*>(y + 2 * p2);
+            *reinterpret_cast<double2*>(&sm.sb[2 * p2]) = make_double2(yy.x + yy.y, yy.x * yy.y);
+          }
+          __syncthreads();
+          const double* yp = sm.sb;
+  asm volatile("; MARK fit_begin");
+          // ---- 6. GPD fit (psis.py:163-208), lane j <-> grid point b_j -------------------------
+          const int mest = 30 + isqrt_i(n);
+          const double yq = y[((n + 2) >> 2) - 1];
+          const double yn = y[n - 1];
+          const bool act = lane < mest;
+          // psis.py:186: 1 - sqrt(m_est / (j - 0.5)); host table for the usual n == M
+          double b = (mest == mestM) ? bgrid[lane] : 1.0 - sqrt((double)mest / ((double)(lane + 1) - 0.5));
+          b = div_fast(b, 3.0 * yq);   // psis.py:187
+          b += recip_fast(yn);         // psis.py:188
+          const double b_first = lane_value(b, 0);  // most negative grid point
+          const double b_last = uniform_d(__shfl(b, mest - 1));
+          const double fbig = fma(-b_first, yn, 1.0), fsmall = fma(-b_last, yn, 1.0);
+          const bool wide = (fbig < 0x1p60) && (fsmall > 0x1p-60);
+          // lanes whose b_j is ~0 would lose the low bits of b_j*y in 1 - b_j*y: carry them along
+          const bool tiny = __ballot(act && fabs(b * yn) < 0.015625) != 0ull;
+  asm volatile("; MARK prod_begin");
+          ProdAcc acc, acc2;
+          acc.init();
+          acc2.init();
+          const double nb = -b;
+          double corr = 0.0;
+          int i = 0;
+          if (wide && !tiny) {
+            for (; i + 8 <= n; i += 8) {
+              const double2 pa = *reinterpret_cast<const double2*>(yp + i);
+              const double2 pb = *reinterpret_cast<const double2*>(yp + i + 2);
+              const double2 pc = *reinterpret_cast<const double2*>(yp + i + 4);
+              const double2 pd = *reinterpret_cast<const double2*>(yp + i + 6);
+              acc.mul(fma(nb, fma(nb, pa.y, pa.x), 1.0));
+              acc2.mul(fma(nb, fma(nb, pb.y, pb.x), 1.0));
+              acc.mul(fma(nb, fma(nb, pc.y, pc.x), 1.0));
+              acc2.mul(fma(nb, fma(nb, pd.y, pd.x), 1.0));
+              acc.renorm();
+              acc2.renorm();
+            }
+            for (; i < n; ++i) acc.mul(fma(nb, y[i], 1.0));
+            acc.renorm();
+          } else {
+            for (; i < n; ++i) {
+              const double yi = y[i];
+              const double f = fma(nb, yi, 1.0);
+              corr += fma(nb, yi, 1.0 - f) * __builtin_amdgcn_rcp(f);  // rounding error of f, relative
+              acc.mul(f);
+              acc.renorm();
+            }
+          }
+  asm volatile("; MARK prod_end");
+          acc.m *= acc2.m;
+          acc.e += acc2.e;
+          const double rn = recip_fast(nn);
+          const double kj = ((log_fast(acc.m) + (double)acc.e * kLn2) + corr) * rn;   // psis.py:190
+          const double ls = nn * (log_fast(-div_fast(b, kj)) - kj - 1.0);             // psis.py:191
+          const double lmax = wave_all<R_MAX>(act ? ls : -INF);
+          // NaN anywhere, or max = +-inf: every weight is NaN in the reference -> nothing is kept
+          const bool anynan = (__ballot(act && (ls != ls)) != 0ull) || !(fabs(lmax) < INF);
+          double w = act ? exp_neg(ls - lmax, sm.tab) : 0.0;                          // psis.py:192
+          const double se = wave_all<R_SUM>(w);
+          w = anynan ? qnan() : w * recip_fast(se);
+          const bool keep = act && (w >= 10.0 * kEps);                                // psis.py:194-197
+          const double sw = wave_all<R_SUM>(keep ? w : 0.0);
+          const double bw = wave_all<R_SUM>(keep ? b * w : 0.0);
+          const double b_post = (sw > 0.0) ? div_fast(bw, sw) : 0.0;                  // psis.py:198,201
+  asm volatile("; MARK kpost_begin");
+          // psis.py:203: mean_i log1p(-b_post*y_i) as the log of per-lane products
+          double pr = 1.0;
+          for (int ii = lane; ii < n; ii += kWave) pr *= fma(-b_post, y[ii], 1.0);
+          const double k_post = wave_all<R_SUM>(log_fast(pr)) * rn;
+          const double sigma = -k_post / b_post;                                      // psis.py:205
+          khat = (nn * k_post + 5.0) / (nn + 10.0);                                   // psis.py:206
+  asm volatile("; MARK smooth_begin");
+          if (isfinite(khat)) {
+            smoothed = true;
+            const double rk = 1.0 / khat;
+            const bool ktiny = fabs(khat) < kEps;
+            for (int j = lane; j < n; j += kWave) {
+              // log1p(-p_j), p_j = (j + 0.5)/n (psis.py:153): host table when n == M
+              const double l1 = (n == M) ? l1tab[j] : log_fast(1.0 - ((double)j + 0.5) * rn);
+              double q;
+              if (sigma <= 0.0) {
+                q = qnan();                                                           // psis.py:214-215
+              } else {
+                q = ktiny ? -l1 : expm1_tab(-khat * l1, sm.tab) * rk;                 // psis.py:218-221
+                q *= sigma;
+              }
+              double wj = q + e_cut;   // exp(log(q + e_cut)), psis.py:155
+              if (wj > 1.0) wj = 1.0;  // psis.py:157
+              const double ej = y[j] + e_cut;
+              acc_t += wj - ej;
+              acc_r += div_fast(wj, ej);
+            }
+          }
+        }
+  asm volatile("; MARK final_begin");
+        // total = sum_nontail e^x + sum_tail w' = (s1 - sum_tail e) + sum_tail w'
+        const double total = wave_all<R_SUM>(s1 + acc_t);
+        s2 = wave_all<R_SUM>(s2);
+        const double L = log_fast(total);                                     // psis.py:158
+        const double A = (-m) - L;
+        double tail_ratio = (double)S;
+        if (smoothed) tail_ratio = (double)(S - n) + wave_all<R_SUM>(acc_r);
+        loo = A + log_fast(tail_ratio);                                       // loo.py:289,319-324
+        lppd = (log_fast(s2) - R) + ((-mn) - logS);                           // loo.py:329-337
+        if ((!(total > 1e-280) || !isfinite(loo) || !isfinite(lppd)) && !(dbgs & 63)) slow = true;
       }
     }
-    if (lane == 0) {
-      if (slow) {
-        const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
-        F.slow_list[idx] = (unsigned)r;
-      } else {
-        if (P.diag) P.diag[r] = khat;
-        if (P.loo_i) P.loo_i[r] = P.scale_value * loo;
-        if (P.lppd_i) P.lppd_i[r] = lppd;
-      }
+  }
+  if (lane == 0) {
+    if (slow) {
+      const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
+      F.slow_list[idx] = (unsigned)r;
+    } else {
+      if (P.diag) P.diag[r] = khat;
+      if (P.loo_i) P.loo_i[r] = P.scale_value * loo;
+      if (P.lppd_i) P.lppd_i[r] = lppd;
     }
+  }
+}
+
+// The per-row body is deliberately NOT inlined into the row loop: inlined, LLVM hoists every
+// loop-invariant constant, mask and offset of the later phases above the loop, where they sit on
+// top of the 128 row registers and spill.
+template <typename T, int VEC>
+__global__ __launch_bounds__(kWave, 2) void wave_loo_kernel(RowsParams P, FastParams F) {
+  __shared__ __attribute__((aligned(16))) WaveSmem sm;
+  const int lane = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < kTabN / kWave; ++i) {
+    const int j = lane + kWave * i;
+    sm.tab[2 * j] = exp2((double)j * (1.0 / kTabN));
+    sm.tab[2 * j + 1] = exp2(-(double)j * (1.0 / kTabN));
+  }
+  __syncthreads();
+  for (int64_t r = blockIdx.x; r < P.n_obs; r += gridDim.x) {
+    const T* rp = reinterpret_cast<const T*>(P.in) + r * P.stride_obs;
+    wave_loo_row<T, VEC>(P, F, sm, r, rp);
   }
 }
 
