@@ -42,6 +42,9 @@ def build(force=False, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [
         _hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
+        # the wave kernel keeps a whole row in registers; hoisting loop-invariant constants out of
+        # its row loop (MachineLICM) pushes it over the register budget and it spills
+        "-mllvm", "-disable-machine-licm",
         "-o", LIB_PATH + ".tmp",
     ] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:

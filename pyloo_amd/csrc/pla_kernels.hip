@@ -173,7 +173,8 @@ static int wave_groups(int S, int vec, int gsz) {
   int g = 0;
   for (int lane = 0; lane < kWave; ++lane)
     for (int i = 0; i < kWaveSlots; i += gsz) {
-      const int s = vec * (lane + kWave * (i / vec)) + (i % vec);
+      const int il = i + gsz - 1;  // last slot of the group: groups must be made of real draws only
+      const int s = vec * (lane + kWave * (il / vec)) + (il % vec);
       if (s < S) ++g;
     }
   return g;
@@ -184,8 +185,9 @@ static int debug_flag(const char* name) {
   return v ? atoi(v) : 0;
 }
 
-template <typename T, int VEC>
-static hipError_t launch_wave(const RowsParams& p, int gsz, hipStream_t stream) {
+template <typename T, int VEC, int GSZ>
+static hipError_t launch_wave(const RowsParams& p, hipStream_t stream) {
+  const int gsz = GSZ;
   hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   static const int dbg = debug_flag("PLA_DEBUG_SKIP");
@@ -195,7 +197,7 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, hipStream_t stream) 
   if (dbg & 64) (void)hipMalloc((void**)&f.dbg, 256 * sizeof(double));
   int64_t grid = p.n_obs;
   if (grid > 2048 * 8) grid = 2048 * 8;
-  hipLaunchKernelGGL((wave_loo_kernel<T, VEC>), dim3((unsigned)grid), dim3(kWave), 0, stream, p, f);
+  hipLaunchKernelGGL((wave_loo_kernel<T, VEC, GSZ>), dim3((unsigned)grid), dim3(kWave), 0, stream, p, f);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (f.dbg) {
@@ -224,8 +226,9 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream) {
     if (path != 1 && path != 2 && unit && waligned && p.method == PLA_PSIS && p.slow_list && p.counters && p.l1_table &&
         p.n_draws <= kWave * kWaveSlots && p.n_draws >= 256 && p.tail_count <= kWaveMaxTail &&
         smem_bytes(BLOCK, p.tail_cap) <= 64 * 1024 && p.n_obs <= 0xffffffffll) {
-      for (int gsz = kWaveSlots; gsz >= 1; gsz >>= 1)
-        if (wave_groups(p.n_draws, WVEC, gsz) >= p.tail_count + 1) return launch_wave<T, WVEC>(p, gsz, stream);
+      // threshold groups of 16 or 8 register slots (compile-time); enough groups guarantee >= M+1 candidates
+      if (wave_groups(p.n_draws, WVEC, 16) >= p.tail_count + 1) return launch_wave<T, WVEC, 16>(p, stream);
+      if (wave_groups(p.n_draws, WVEC, 8) >= p.tail_count + 1) return launch_wave<T, WVEC, 8>(p, stream);
     }
     if (path == 1) return launch_one<T, BLOCK, 0, LW>(p, stream);
   }

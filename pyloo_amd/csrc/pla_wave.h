@@ -30,7 +30,7 @@
 #include "pla_math.h"
 
 #ifndef PLA_ROW_INLINE
-#define PLA_ROW_INLINE __attribute__((noinline))
+#define PLA_ROW_INLINE __forceinline__
 #endif
 
 namespace pla {
@@ -92,7 +92,7 @@ __device__ __forceinline__ double wave_all(double v) {
 }
 
 struct WaveSmem {
-  unsigned hist[kWaveBins];
+  unsigned hist[kWaveBins + kWave];  // + one private dummy bin per lane for draws below the threshold
   unsigned start[kWaveBins];
   double sa[kWaveCap];
   double sb[kWaveCap];
@@ -108,16 +108,39 @@ __device__ __forceinline__ double add_hi(double v, int d) {  // v * 2^(d >> 20) 
   return __hiloint2double(__double2hiint(v) + d, __double2loint(v));
 }
 
+// Issue the 16-byte buffer loads of one row into the register slots (slot q*VEC+e holds draw
+// VEC*(lane + 64 q) + e).  The row is the bounds-checked range of the buffer descriptor: one VGPR
+// offset (lane*16), scalar per-q offsets, zeros past the end.  Nothing waits here: the loads stay
+// in flight until the slots are first used.
 template <typename T, int VEC>
+__device__ __forceinline__ void issue_row_loads(T (&v)[kWaveSlots], const T* rp, int S) {
+  constexpr int NQ = kWaveSlots / VEC;
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(rp), 0, S * (int)sizeof(T), 0x00020000);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const v4i t = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, q * (kWave * 16), 2 /* nt */);
+    if constexpr (VEC == 2) {
+      v[2 * q] = (T)__hiloint2double(t[1], t[0]);
+      v[2 * q + 1] = (T)__hiloint2double(t[3], t[2]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * q + e] = (T)__int_as_float(t[e]);
+    }
+  }
+}
+
+template <typename T, int VEC, int GSZ>
 __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParams& F, WaveSmem& sm, const int64_t r,
-                                            const T* rp) {
+                                            T (&v)[kWaveSlots], const T* rp_next) {
   constexpr int EPT = kWaveSlots;
   constexpr int NQ = EPT / VEC;
   const int lane = threadIdx.x;
   // parameters arrive by reference (memory): read each once into scalar registers
   const int S = __builtin_amdgcn_readfirstlane(P.n_draws);
   const int M = __builtin_amdgcn_readfirstlane(P.tail_count);
-  const int gsz = __builtin_amdgcn_readfirstlane(F.gsz);
 #if PLA_WAVE_ABLATE
   const int dbgs = __builtin_amdgcn_readfirstlane(F.debug_skip);
 #else
@@ -131,25 +154,9 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   const int nvec = S / VEC;                       // 16-byte vectors per row (S % VEC == 0)
   const int qfull = nvec / kWave;                 // q < qfull: every lane valid
   const int qrem = nvec - qfull * kWave;          // q == qfull: lanes < qrem valid
-  typedef int v4i __attribute__((ext_vector_type(4)));
 
-  // ---- load: slot q*VEC+e holds draw VEC*(lane + 64 q) + e.  Buffer loads with the row as the
-  // bounds-checked range: one VGPR offset (lane*16), scalar per-q offsets, zeros past the row.
-  T v[EPT];
+  // ---- finish the load issued by the previous iteration (or the prologue): pad fix-up -------------
   {
-    const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(rp), 0, S * (int)sizeof(T), 0x00020000);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const v4i t = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, q * (kWave * 16), 2 /* nt */);
-      if constexpr (VEC == 2) {
-        v[2 * q] = (T)__hiloint2double(t[1], t[0]);
-        v[2 * q + 1] = (T)__hiloint2double(t[3], t[2]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[4 * q + e] = (T)__int_as_float(t[e]);
-      }
-    }
     // slots past the row: copy this lane's first vector (harmless for max / min / threshold)
 #pragma unroll
     for (int q = 1; q < NQ; ++q) {
@@ -173,7 +180,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       gcur = vmax_nc<true>(v[i], gcur);
       vmx = vmax_nc<false>(v[i], vmx);
       chk = fma_t(v[i], T(0), chk);
-      if (((i + 1) & (gsz - 1)) == 0) {
+      if (((i + 1) & (GSZ - 1)) == 0) {  // compile-time: the loop is fully unrolled
         // a group made only of pads repeats this lane's first draws: it can only lower gmin
         gmn = -vmax_nc<true>(gcur, -gmn);  // min(gmn, gcur)
         gmx = vmax_nc<false>(gcur, gmx);
@@ -197,6 +204,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   const int kpad = key256(-R);               // key of the pad value (smallest x of the row)
   if (kpad >= k1) slow = true;               // pads would be counted as candidates
   double khat = INF, loo = 0.0, lppd = 0.0;
+  bool prefetched = false;
   if (!slow) {
   asm volatile("; MARK setup_begin");
     // bins: (k - k1) >> sh  in [0, 1023] for k in [k1, 0]
@@ -242,10 +250,12 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         s1 += add_hi(tt.x * fma(rr, O, E), es);
         s2 += add_hi(tt.y * fma(-rr, O, E), -es);
       }
-      if (k >= k1 && !(dbgs & 2)) atomicAdd(&sm.hist[(k - k1) >> sh], one);
+      // branch-free: draws below the threshold count into the lane's own dummy bin, so the 64 draws
+      // form one basic block the scheduler can interleave
+      atomicAdd(&sm.hist[(k >= k1) ? ((k - k1) >> sh) : (kWaveBins + lane)], one);
       // pin the running sums here: otherwise the whole accumulation chain is sunk below the 64
       // histogram branches and its inputs (table entries, reduced arguments) spill
-      asm volatile("" : "+v"(s1), "+v"(s2));
+      if ((i & 3) == 3) asm volatile("" : "+v"(s1), "+v"(s2));
     }
   asm volatile("; MARK sweep_end");
     {  // remove the pads' contribution (same code path, so it cancels to rounding)
@@ -473,6 +483,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       }
     }
   }
+  if (!prefetched && rp_next) issue_row_loads<T, VEC>(v, rp_next, S);
   if (lane == 0) {
     if (slow) {
       const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
@@ -488,7 +499,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
 // The per-row body is deliberately NOT inlined into the row loop: inlined, LLVM hoists every
 // loop-invariant constant, mask and offset of the later phases above the loop, where they sit on
 // top of the 128 row registers and spill.
-template <typename T, int VEC>
+template <typename T, int VEC, int GSZ>
 __global__ __launch_bounds__(kWave, 2) void wave_loo_kernel(RowsParams P, FastParams F) {
   __shared__ __attribute__((aligned(16))) WaveSmem sm;
   const int lane = threadIdx.x;
@@ -499,9 +510,12 @@ __global__ __launch_bounds__(kWave, 2) void wave_loo_kernel(RowsParams P, FastPa
     sm.tab[2 * j + 1] = exp2(-(double)j * (1.0 / kTabN));
   }
   __syncthreads();
+  T v[kWaveSlots];
+  const T* base = reinterpret_cast<const T*>(P.in);
+  if ((int64_t)blockIdx.x < P.n_obs) issue_row_loads<T, VEC>(v, base + (int64_t)blockIdx.x * P.stride_obs, P.n_draws);
   for (int64_t r = blockIdx.x; r < P.n_obs; r += gridDim.x) {
-    const T* rp = reinterpret_cast<const T*>(P.in) + r * P.stride_obs;
-    wave_loo_row<T, VEC>(P, F, sm, r, rp);
+    const int64_t rn = r + gridDim.x;
+    wave_loo_row<T, VEC, GSZ>(P, F, sm, r, v, rn < P.n_obs ? base + rn * P.stride_obs : nullptr);
   }
 }
 
