@@ -40,9 +40,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    lib_path = os.environ.get("PYLOO_AMD_LIB", LIB_PATH)  # profiling builds (tools/ablate.sh)
+    if not os.path.exists(lib_path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: the HIP engine has not been built "
+            f"{lib_path} is missing: the HIP engine has not been built "
             "(run `python -m pyloo_amd.build`).  pyloo_amd has no CPU fallback."
         )
     # PyTorch-ROCm wheels bundle their own HIP runtime (same SONAME libamdhip64.so.7).  Two HIP
@@ -53,7 +54,7 @@ def load_library():
         import torch  # noqa: F401
     except Exception:  # torch is optional for pure NumPy callers
         pass
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(lib_path)
     i64, dbl, vp, ci = C.c_int64, C.c_double, C.c_void_p, C.c_int
     lib.pla_abi_version.restype = ci
     lib.pla_last_error.restype = C.c_char_p

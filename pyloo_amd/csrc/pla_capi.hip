@@ -43,6 +43,7 @@ int pow2_at_least(int64_t n) {
 struct pla_engine {
   int device = 0;
   unsigned long long* counters = nullptr;  // [4] device
+  double* d_red = nullptr;                 // reduction partials
   // staging for PLA_HOST callers (grown on demand)
   void* d_in = nullptr;
   size_t d_in_bytes = 0;
@@ -178,6 +179,7 @@ int pla_engine_create(int device, pla_engine** out) {
   if (!e) return fail(PLA_ERR_NOMEM, "out of host memory");
   e->device = device;
   hipError_t he = hipMalloc((void**)&e->counters, 4 * sizeof(unsigned long long));
+  if (he == hipSuccess) he = hipMalloc((void**)&e->d_red, (size_t)pla::reduce_workspace_doubles() * sizeof(double));
   if (he == hipSuccess) he = hipMemset(e->counters, 0, 4 * sizeof(unsigned long long));
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
   if (he == hipSuccess) he = hipEventCreate(&e->ev1);
@@ -193,6 +195,7 @@ int pla_engine_destroy(pla_engine* e) {
   if (!e) return PLA_OK;
   (void)hipSetDevice(e->device);
   if (e->counters) (void)hipFree(e->counters);
+  if (e->d_red) (void)hipFree(e->d_red);
   if (e->d_in) (void)hipFree(e->d_in);
   if (e->d_lw) (void)hipFree(e->d_lw);
   if (e->d_pw) (void)hipFree(e->d_pw);
@@ -240,7 +243,7 @@ int pla_reduce_pointwise(pla_engine* eng, const double* diag, const double* loo_
   hipStream_t s = (hipStream_t)stream;
   if (mem_space == PLA_DEVICE) {
     pla::ReduceParams rp{diag, loo_i, lppd_i, n_obs, good_k, agg, nullptr};
-    PLA_HIP(pla::launch_reduce(rp, s));
+    PLA_HIP(pla::launch_reduce(rp, eng->d_red, s));
     return PLA_OK;
   }
   const size_t need = (size_t)(3 * n_obs + PLA_AGG_COUNT);
@@ -255,7 +258,7 @@ int pla_reduce_pointwise(pla_engine* eng, const double* diag, const double* loo_
   if (lppd_i) { dp = d + 2 * n_obs; PLA_HIP(hipMemcpyAsync(dp, lppd_i, n_obs * sizeof(double), hipMemcpyHostToDevice, s)); }
   double* dagg = d + 3 * n_obs;
   pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, dagg, nullptr};
-  PLA_HIP(pla::launch_reduce(rp, s));
+  PLA_HIP(pla::launch_reduce(rp, eng->d_red, s));
   PLA_HIP(hipMemcpyAsync(agg, dagg, PLA_AGG_COUNT * sizeof(double), hipMemcpyDeviceToHost, s));
   PLA_HIP(hipStreamSynchronize(s));
   return PLA_OK;
@@ -313,7 +316,7 @@ int pla_psis_loo(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int6
     }
     if (agg) {
       pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, agg, eng->counters};
-      PLA_HIP(pla::launch_reduce(rp, s));
+      PLA_HIP(pla::launch_reduce(rp, eng->d_red, s));
     }
     return PLA_OK;
   }
@@ -367,7 +370,7 @@ int pla_psis_loo(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int6
   }
   if (agg) {
     pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, dagg, nullptr};
-    PLA_HIP(pla::launch_reduce(rp, s));
+    PLA_HIP(pla::launch_reduce(rp, eng->d_red, s));
     PLA_HIP(hipMemcpyAsync(agg, dagg, PLA_AGG_COUNT * sizeof(double), hipMemcpyDeviceToHost, s));
   }
   PLA_HIP(hipStreamSynchronize(s));

@@ -37,7 +37,8 @@ struct ReduceParams {
 
 // returns hipSuccess or the launch error; never synchronises
 hipError_t launch_rows(const RowsParams& p, int dtype, bool lw_mode, hipStream_t stream);
-hipError_t launch_reduce(const ReduceParams& p, hipStream_t stream);
+hipError_t launch_reduce(const ReduceParams& p, double* workspace, hipStream_t stream);
+int reduce_workspace_doubles();  // size of `workspace` (device memory)
 hipError_t launch_fill_synthetic(void* ll, int dtype, int64_t n_obs, int64_t n_draws, int64_t row0,
                                  uint64_t seed, double k_lo, double k_hi, double heavy_lo,
                                  double heavy_hi, hipStream_t stream);

@@ -55,14 +55,22 @@ __global__ __launch_bounds__(BLOCK) void slow_rows_kernel(RowsParams P) {
   }
 }
 
-// loo.py:326-342 + 292-293: one workgroup, two deterministic passes (sum, then squared
-// deviations about the mean: np.var is a two-pass formula as well).
-constexpr int kRedBlock = 1024;
-__global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceParams P) {
+// loo.py:326-342 + 292-293 in two deterministic launches.  Stage 1: every workgroup reduces its own
+// contiguous chunk to (n, sum, M2 about the chunk mean, ...); np.var is a two-pass formula as well
+// and the chunk is L2-resident for the second pass.  Stage 2: one workgroup merges the chunk moments
+// in chunk order with the pairwise update of Chan, Golub & LeVeque (no cancellation).
+constexpr int kRedBlock = 256;
+constexpr int kRedChunks = 1024;
+constexpr int kRedSlots = 8;  // n, sum loo, M2, sum lppd, #high, #non-finite, min diag, unused
+
+__global__ __launch_bounds__(kRedBlock) void reduce_stage1(ReduceParams P, double* part) {
   __shared__ double red[16];
   const int tid = threadIdx.x;
+  const int64_t per = (P.n_obs + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per;
+  const int64_t hi = (lo + per < P.n_obs) ? lo + per : P.n_obs;
   double s_loo = 0.0, s_lppd = 0.0, n_high = 0.0, n_bad = 0.0, dmin = pinf();
-  for (int64_t i = tid; i < P.n_obs; i += kRedBlock) {
+  for (int64_t i = lo + tid; i < hi; i += kRedBlock) {
     if (P.loo_i) s_loo += P.loo_i[i];
     if (P.lppd_i) s_lppd += P.lppd_i[i];
     if (P.diag) {
@@ -77,24 +85,46 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceParams P) {
   n_high = block_reduce<OpSum, kRedBlock>(n_high, red);
   n_bad = block_reduce<OpSum, kRedBlock>(n_bad, red);
   dmin = block_reduce<OpMin, kRedBlock>(dmin, red);
-  const double mean = s_loo / (double)P.n_obs;
+  const double cnt = (double)(hi > lo ? hi - lo : 0);
+  const double mean = cnt > 0 ? s_loo / cnt : 0.0;
   double m2 = 0.0;
   if (P.loo_i)
-    for (int64_t i = tid; i < P.n_obs; i += kRedBlock) {
+    for (int64_t i = lo + tid; i < hi; i += kRedBlock) {
       const double d = P.loo_i[i] - mean;
       m2 += d * d;
     }
   m2 = block_reduce<OpSum, kRedBlock>(m2, red);
   if (tid == 0) {
-    P.agg[PLA_AGG_N] = (double)P.n_obs;
-    P.agg[PLA_AGG_SUM_LOO] = s_loo;
-    P.agg[PLA_AGG_M2_LOO] = m2;
-    P.agg[PLA_AGG_SUM_LPPD] = s_lppd;
-    P.agg[PLA_AGG_N_HIGH] = n_high;
-    P.agg[PLA_AGG_N_NONFINITE] = n_bad;
-    P.agg[PLA_AGG_MIN_DIAG] = dmin;
-    P.agg[PLA_AGG_N_SLOW] = P.counters ? (double)P.counters[0] : 0.0;
+    double* o = part + (size_t)blockIdx.x * kRedSlots;
+    o[0] = cnt; o[1] = s_loo; o[2] = m2; o[3] = s_lppd; o[4] = n_high; o[5] = n_bad; o[6] = dmin; o[7] = 0.0;
   }
+}
+
+__global__ __launch_bounds__(kWave) void reduce_stage2(ReduceParams P, const double* part, int nchunks) {
+  if (threadIdx.x != 0) return;  // a few hundred serial flops: determinism over parallelism
+  double n = 0.0, mean = 0.0, m2 = 0.0, s_loo = 0.0, s_lppd = 0.0, n_high = 0.0, n_bad = 0.0, dmin = pinf();
+  for (int c = 0; c < nchunks; ++c) {
+    const double* o = part + (size_t)c * kRedSlots;
+    const double nb = o[0];
+    if (nb == 0.0) continue;
+    const double mb = o[1] / nb;
+    if (n == 0.0) { n = nb; mean = mb; m2 = o[2]; }
+    else {
+      const double delta = mb - mean, tot = n + nb;
+      m2 += o[2] + delta * delta * n * nb / tot;
+      mean += delta * nb / tot;
+      n = tot;
+    }
+    s_loo += o[1]; s_lppd += o[3]; n_high += o[4]; n_bad += o[5]; dmin = fmin(dmin, o[6]);
+  }
+  P.agg[PLA_AGG_N] = (double)P.n_obs;
+  P.agg[PLA_AGG_SUM_LOO] = s_loo;
+  P.agg[PLA_AGG_M2_LOO] = m2;
+  P.agg[PLA_AGG_SUM_LPPD] = s_lppd;
+  P.agg[PLA_AGG_N_HIGH] = n_high;
+  P.agg[PLA_AGG_N_NONFINITE] = n_bad;
+  P.agg[PLA_AGG_MIN_DIAG] = dmin;
+  P.agg[PLA_AGG_N_SLOW] = P.counters ? (double)P.counters[0] : 0.0;
 }
 
 template <typename T>
@@ -253,8 +283,16 @@ hipError_t launch_rows(const RowsParams& p, int dtype, bool lw_mode, hipStream_t
   return lw_mode ? launch_typed<float, true>(p, stream) : launch_typed<float, false>(p, stream);
 }
 
-hipError_t launch_reduce(const ReduceParams& p, hipStream_t stream) {
-  hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(kRedBlock), 0, stream, p);
+int reduce_workspace_doubles() { return kRedChunks * kRedSlots; }
+
+hipError_t launch_reduce(const ReduceParams& p, double* workspace, hipStream_t stream) {
+  int64_t chunks = (p.n_obs + 1023) / 1024;  // >= 1024 observations per chunk
+  if (chunks < 1) chunks = 1;
+  if (chunks > kRedChunks) chunks = kRedChunks;
+  hipLaunchKernelGGL(reduce_stage1, dim3((unsigned)chunks), dim3(kRedBlock), 0, stream, p, workspace);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(reduce_stage2, dim3(1), dim3(kWave), 0, stream, p, workspace, (int)chunks);
   return hipGetLastError();
 }
 

@@ -54,17 +54,20 @@ __device__ __forceinline__ double exp_neg(double x, const double* tab) { return 
 // subtraction loses at most 5 bits there).  z > 709 -> +inf, z < -700 -> -1.  NaN -> NaN.
 __device__ __forceinline__ double expm1_tab(double z, const double* tab) {
   const double zc = fmin(fmax(z, -700.0), 709.0);
-  double p = 2.75573192239858906526e-06;  // 1/9!
-  p = fma(p, zc, 2.48015873015873015873e-05);
-  p = fma(p, zc, 1.98412698412698412698e-04);
-  p = fma(p, zc, 1.38888888888888888889e-03);
-  p = fma(p, zc, 8.33333333333333333333e-03);
-  p = fma(p, zc, 4.16666666666666666667e-02);
-  p = fma(p, zc, 1.66666666666666666667e-01);
-  p = fma(p, zc, 0.5);
-  p = fma(p * zc, zc, zc);
-  const double big = exp_tab(zc, tab) - 1.0;
-  double res = (fabs(zc) < 0.03125) ? p : big;
+  double res = exp_tab(zc, tab) - 1.0;
+  const bool small = fabs(zc) < 0.03125;
+  if (__builtin_amdgcn_ballot_w64(small) != 0ull) {  // wave-uniform: most calls have no small argument
+    double p = 2.75573192239858906526e-06;  // 1/9!
+    p = fma(p, zc, 2.48015873015873015873e-05);
+    p = fma(p, zc, 1.98412698412698412698e-04);
+    p = fma(p, zc, 1.38888888888888888889e-03);
+    p = fma(p, zc, 8.33333333333333333333e-03);
+    p = fma(p, zc, 4.16666666666666666667e-02);
+    p = fma(p, zc, 1.66666666666666666667e-01);
+    p = fma(p, zc, 0.5);
+    p = fma(p * zc, zc, zc);
+    if (small) res = p;
+  }
   if (z > 709.0) res = pinf();
   if (z != z) res = z;
   return res;

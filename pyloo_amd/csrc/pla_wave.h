@@ -93,10 +93,12 @@ __device__ __forceinline__ double wave_all(double v) {
 
 struct WaveSmem {
   unsigned hist[kWaveBins + kWave];  // + one private dummy bin per lane for draws below the threshold
-  unsigned start[kWaveBins];
+  unsigned short start[kWaveBins];  // #draws in bins above b (<= 4096)
   double sa[kWaveCap];
   double sb[kWaveCap];
   double tab[2 * kTabN];  // {2^(j/256), 2^(-j/256)} interleaved: one 16-byte read serves both exponentials
+  double l1[kWaveMaxTail + 6];  // log1p(-(j+0.5)/M), j < M  (host libm, psis.py:153,219-221)
+  double bg[kWave];             // 1 - sqrt(m_est/(j+0.5)) for m_est(M)  (psis.py:186)
 };
 
 // phase ablation for profiling (tools/ablate.sh); compiled out of the production kernel
@@ -146,8 +148,8 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
 #else
   constexpr int dbgs = 0;
 #endif
-  const double* l1tab = F.l1_table;
-  const double* bgrid = F.b_grid;
+  const double* l1tab = sm.l1;
+  const double* bgrid = sm.bg;
   const int mestM = __builtin_amdgcn_readfirstlane(F.mest_M);
   const double logS = uniform_d(F.log_S);
   const double INF = pinf();
@@ -169,17 +171,15 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   }
   asm volatile("; MARK stats_begin");
   // ---- 1. row statistics, in the input precision (exact; duplicates of valid draws are harmless) ---
-  // raw = -ll:  max raw = max(-v),  min raw = -max(v).  chk = sum v*0 is NaN iff some v is NaN/+-inf.
+  // raw = -ll:  max raw = max(-v),  min raw = -max(v)
   double mx, mn, gmin;
-  bool bad;
   {
     const T ninf = (T)(-INF);
-    T gcur = ninf, vmx = ninf, gmx = ninf, gmn = (T)INF, chk = T(0);
+    T gcur = ninf, vmx = ninf, gmx = ninf, gmn = (T)INF;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
       gcur = vmax_nc<true>(v[i], gcur);
       vmx = vmax_nc<false>(v[i], vmx);
-      chk = fma_t(v[i], T(0), chk);
       if (((i + 1) & (GSZ - 1)) == 0) {  // compile-time: the loop is fully unrolled
         // a group made only of pads repeats this lane's first draws: it can only lower gmin
         gmn = -vmax_nc<true>(gcur, -gmn);  // min(gmn, gcur)
@@ -190,16 +190,16 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     mx = (double)gmx;
     mn = -(double)vmx;
     gmin = (double)gmn;
-    bad = chk != chk;
   }
   asm volatile("; MARK stats_end");
   const double m = wave_all<R_MAX>(mx);
   mn = wave_all<R_MIN>(mn);
   gmin = wave_all<R_MIN>(gmin);
-  const bool anybad = __ballot(bad) != 0ull;
   const double R = m - mn;
   const double t1 = gmin - m;
-  bool slow = anybad || !(R < kWaveMaxRange) || !(t1 < 0.0);
+  // +-inf in the row makes R inf/NaN; a NaN draw is ignored by v_max here, poisons s1 in the sweep
+  // and is caught by the finiteness test at the end: both land on the general kernel
+  bool slow = !(R < kWaveMaxRange) || !(t1 < 0.0);
   const int k1 = key256(t1);                 // histogram origin
   const int kpad = key256(-R);               // key of the pad value (smallest x of the row)
   if (kpad >= k1) slow = true;               // pads would be counted as candidates
@@ -235,27 +235,42 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     double magic = kMagic;
     unsigned one = 1u;
     asm volatile("" : "+v"(magic), "+v"(one));  // keep both resident instead of re-materialising per draw
+    // Software pipeline, kPF draws deep: stage A of draw i+kPF (shift, range reduction, table read,
+    // histogram count) is issued before stage B of draw i (polynomial, accumulate), so the LDS
+    // latency of the table read is covered by the arithmetic of the draws in between.
+    constexpr int kPF = 3;
+    double px[kPF], pt[kPF];
+    double2 ptt[kPF];
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      const double x = (-(double)v[i]) - m;  // psis.py:134
-      const double t = fma(x, kC256, magic);
-      const int k = __double2loint(t);        // round(x * 256/ln2): low mantissa bits of t
-      if (!(dbgs & 1)) {
+    for (int i = 0; i < EPT + kPF; ++i) {
+      if (i >= kPF) {  // stage B of draw i - kPF
+        const int sl = (i - kPF) % kPF;
+        const double x = px[sl], t = pt[sl];
+        const int k = __double2loint(t);
         const double rr = fma(t - magic, -kLn2_256, x);
-        const double2 tt = *reinterpret_cast<const double2*>(tab + 2 * (k & 255));
         const double r2 = rr * rr;
         const double E = fma(fma(4.16666666666666666667e-02, r2, 0.5), r2, 1.0);
         const double O = fma(1.66666666666666666667e-01, r2, 1.0);
-        const int es = (k << 12) & 0xfff00000;  // (k >> 8) << 20
-        s1 += add_hi(tt.x * fma(rr, O, E), es);
-        s2 += add_hi(tt.y * fma(-rr, O, E), -es);
+        const int es = (k << 12) & 0xfff00000;  // (k >> 8) << 20: 2^(k >> 8) goes into the table entry
+        if (!(dbgs & 1)) {
+          s1 = fma(add_hi(ptt[sl].x, es), fma(rr, O, E), s1);
+          s2 = fma(add_hi(ptt[sl].y, -es), fma(-rr, O, E), s2);
+        }
+        // pin the running sums: otherwise the accumulation chain is sunk to the end of the block and
+        // its inputs (table entries, reduced arguments) spill
+        if ((i & 3) == 3) asm volatile("" : "+v"(s1), "+v"(s2));
       }
-      // branch-free: draws below the threshold count into the lane's own dummy bin, so the 64 draws
-      // form one basic block the scheduler can interleave
-      atomicAdd(&sm.hist[(k >= k1) ? ((k - k1) >> sh) : (kWaveBins + lane)], one);
-      // pin the running sums here: otherwise the whole accumulation chain is sunk below the 64
-      // histogram branches and its inputs (table entries, reduced arguments) spill
-      if ((i & 3) == 3) asm volatile("" : "+v"(s1), "+v"(s2));
+      if (i < EPT) {  // stage A of draw i
+        const int sl = i % kPF;
+        const double x = (-(double)v[i]) - m;  // psis.py:134
+        const double t = fma(x, kC256, magic);
+        const int k = __double2loint(t);       // round(x * 256/ln2): low mantissa bits of t
+        px[sl] = x;
+        pt[sl] = t;
+        ptt[sl] = *reinterpret_cast<const double2*>(tab + 2 * (k & 255));
+        // branch-free: draws below the threshold count into the lane's own dummy bin
+        if (!(dbgs & 2)) atomicAdd(&sm.hist[(k >= k1) ? ((k - k1) >> sh) : (kWaveBins + lane)], one);
+      }
     }
   asm volatile("; MARK sweep_end");
     {  // remove the pads' contribution (same code path, so it cancels to rounding)
@@ -270,8 +285,8 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       const int es = (k << 12) & 0xfff00000;
       const double npad = (double)((NQ - qfull) * VEC - ((lane < qrem) ? VEC : 0));  // padded slots of this lane
       if (!(dbgs & 1)) {
-        s1 -= npad * add_hi(tt.x * fma(rr, O, E), es);
-        s2 -= npad * add_hi(tt.y * fma(-rr, O, E), -es);
+        s1 = fma(-npad * add_hi(tt.x, es), fma(rr, O, E), s1);
+        s2 = fma(-npad * add_hi(tt.y, -es), fma(-rr, O, E), s2);
       }
     }
     __syncthreads();
@@ -310,8 +325,10 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           a += c[i];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          *reinterpret_cast<uint4*>(&sm.start[16 * lane + 4 * i]) = make_uint4(st[4 * i], st[4 * i + 1], st[4 * i + 2], st[4 * i + 3]);
+        for (int i = 0; i < 2; ++i)
+          *reinterpret_cast<uint4*>(&sm.start[16 * lane + 8 * i]) =
+              make_uint4(st[8 * i] | (st[8 * i + 1] << 16), st[8 * i + 2] | (st[8 * i + 3] << 16),
+                         st[8 * i + 4] | (st[8 * i + 5] << 16), st[8 * i + 6] | (st[8 * i + 7] << 16));
         const unsigned long long who = __ballot(fb >= 0);
         const int src = __ffsll((long long)who) - 1;
         bstar = __builtin_amdgcn_readlane(fb, src);
@@ -473,11 +490,10 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         // total = sum_nontail e^x + sum_tail w' = (s1 - sum_tail e) + sum_tail w'
         const double total = wave_all<R_SUM>(s1 + acc_t);
         s2 = wave_all<R_SUM>(s2);
-        const double L = log_fast(total);                                     // psis.py:158
-        const double A = (-m) - L;
+        // loo_i = -m - L + log(tail_ratio),  L = log(total) (psis.py:158; loo.py:289,319-324): one log
         double tail_ratio = (double)S;
         if (smoothed) tail_ratio = (double)(S - n) + wave_all<R_SUM>(acc_r);
-        loo = A + log_fast(tail_ratio);                                       // loo.py:289,319-324
+        loo = log_fast(div_fast(tail_ratio, total)) - m;
         lppd = (log_fast(s2) - R) + ((-mn) - logS);                           // loo.py:329-337
         if ((!(total > 1e-280) || !isfinite(loo) || !isfinite(lppd)) && !(dbgs & 63)) slow = true;
       }
@@ -509,6 +525,8 @@ __global__ __launch_bounds__(kWave, 2) void wave_loo_kernel(RowsParams P, FastPa
     sm.tab[2 * j] = exp2((double)j * (1.0 / kTabN));
     sm.tab[2 * j + 1] = exp2(-(double)j * (1.0 / kTabN));
   }
+  for (int j = lane; j < P.tail_count; j += kWave) sm.l1[j] = F.l1_table[j];
+  sm.bg[lane] = F.b_grid[lane];
   __syncthreads();
   T v[kWaveSlots];
   const T* base = reinterpret_cast<const T*>(P.in);
