@@ -168,37 +168,6 @@ static hipError_t launch_one(const RowsParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// number of non-empty threshold groups of the fast kernel for a given group size
-static int fast_groups(int S, int ept, int vec, int gsz) {
-  int g = 0;
-  for (int tid = 0; tid < kFastBlock; ++tid)
-    for (int i = 0; i < ept; i += gsz) {
-      const int s = vec * (tid + kFastBlock * (i / vec)) + (i % vec);
-      if (s < S) ++g;
-    }
-  return g;
-}
-
-template <typename T, int EPT, int VEC>
-static hipError_t launch_fast(const RowsParams& p, int gsz, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
-  if (e != hipSuccess) return e;
-  static const int dbg = getenv("PLA_DEBUG_SKIP") ? atoi(getenv("PLA_DEBUG_SKIP")) : 0;
-  FastParams f{gsz, p.slow_list, p.counters, dbg, nullptr, nullptr, 0.0, nullptr, 0};
-  int64_t grid = p.n_obs;
-  if (grid > 256 * 32) grid = 256 * 32;
-  hipLaunchKernelGGL((fast_loo_kernel<T, EPT, VEC>), dim3((unsigned)grid), dim3(kFastBlock), fast_smem_bytes(),
-                     stream, p, f);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  // general kernel over whatever the fast path declined (usually nothing)
-  constexpr int BLOCK = 256;
-  int64_t g2 = p.n_obs < 1024 ? p.n_obs : 1024;
-  hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap),
-                     stream, p);
-  return hipGetLastError();
-}
-
 static int wave_groups(int S, int vec, int gsz) {
   int g = 0;
   for (int lane = 0; lane < kWave; ++lane)
@@ -221,23 +190,18 @@ static hipError_t launch_wave(const RowsParams& p, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   static const int dbg = debug_flag("PLA_DEBUG_SKIP");
-  int root_ = (int)std::sqrt((double)p.tail_count); while (root_ * root_ > p.tail_count) --root_; while ((root_ + 1) * (root_ + 1) <= p.tail_count) ++root_;
+  int root_ = (int)std::sqrt((double)p.tail_count);
+  while (root_ * root_ > p.tail_count) --root_;
+  while ((root_ + 1) * (root_ + 1) <= p.tail_count) ++root_;
   const int mestM = 30 + root_;
-  FastParams f{gsz, p.slow_list, p.counters, dbg, nullptr, p.l1_table, std::log((double)p.n_draws), p.l1_table + p.tail_count, mestM};
-  if (dbg & 64) (void)hipMalloc((void**)&f.dbg, 256 * sizeof(double));
+  FastParams f{gsz, p.slow_list, p.counters, dbg, p.l1_table, std::log((double)p.n_draws), p.l1_table + p.tail_count, mestM};
+  // one wave per workgroup; 8 x 2048 workgroups keep all 256 CUs (8 waves each) busy with a short tail
   int64_t grid = p.n_obs;
   if (grid > 2048 * 8) grid = 2048 * 8;
   hipLaunchKernelGGL((wave_loo_kernel<T, VEC, GSZ>), dim3((unsigned)grid), dim3(kWave), 0, stream, p, f);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  if (f.dbg) {
-    double h[256];
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(h, f.dbg, sizeof(h), hipMemcpyDeviceToHost);
-    for (int i = 0; i < 30; ++i) fprintf(stderr, "DBG[%d] = %.17g\n", i, h[i]);
-    
-    (void)hipFree(f.dbg);
-  }
+  // general kernel over whatever the fast path declined (usually nothing)
   constexpr int BLOCK = 256;
   int64_t g2 = p.n_obs < 1024 ? p.n_obs : 1024;
   hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap),
@@ -250,10 +214,10 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream) {
   constexpr int BLOCK = 256;
   const bool unit = (p.stride_draw == 1);
   if constexpr (!LW) {
-    static const int path = debug_flag("PLA_FORCE_PATH");  // 0 auto, 1 general, 2 block-fast, 3 wave
+    static const int path = debug_flag("PLA_FORCE_PATH");  // 0 auto, 1 general kernel only (tests)
     constexpr int WVEC = 16 / sizeof(T);
     const bool waligned = ((uintptr_t)p.in % 16 == 0) && (p.stride_obs % WVEC == 0) && (p.n_draws % WVEC == 0);
-    if (path != 1 && path != 2 && unit && waligned && p.method == PLA_PSIS && p.slow_list && p.counters && p.l1_table &&
+    if (path != 1 && unit && waligned && p.method == PLA_PSIS && p.slow_list && p.counters && p.l1_table &&
         p.n_draws <= kWave * kWaveSlots && p.n_draws >= 256 && p.tail_count <= kWaveMaxTail &&
         smem_bytes(BLOCK, p.tail_cap) <= 64 * 1024 && p.n_obs <= 0xffffffffll) {
       // threshold groups of 16 or 8 register slots (compile-time); enough groups guarantee >= M+1 candidates
@@ -261,17 +225,6 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream) {
       if (wave_groups(p.n_draws, WVEC, 8) >= p.tail_count + 1) return launch_wave<T, WVEC, 8>(p, stream);
     }
     if (path == 1) return launch_one<T, BLOCK, 0, LW>(p, stream);
-  }
-  if constexpr (!LW) {
-    constexpr int VEC = 16 / sizeof(T);
-    constexpr int EPT = 16;
-    const bool aligned = ((uintptr_t)p.in % 16 == 0) && (p.stride_obs % VEC == 0) && (p.n_draws % VEC == 0);
-    if (unit && aligned && p.method == PLA_PSIS && p.slow_list && p.counters && p.n_draws <= kFastBlock * EPT &&
-        p.n_draws >= 512 && p.tail_count + 1 <= kFastCap - 64 && smem_bytes(BLOCK, p.tail_cap) <= 64 * 1024 &&
-        p.n_obs <= 0xffffffffll) {
-      for (int gsz = EPT; gsz >= 1; gsz >>= 1)
-        if (fast_groups(p.n_draws, EPT, VEC, gsz) >= p.tail_count + 1) return launch_fast<T, EPT, VEC>(p, gsz, stream);
-    }
   }
   if (unit && p.n_draws <= BLOCK * 16 && p.n_draws > BLOCK * 4) return launch_one<T, BLOCK, 16, LW>(p, stream);
   return launch_one<T, BLOCK, 0, LW>(p, stream);

@@ -99,6 +99,9 @@ struct WaveSmem {
   double tab[2 * kTabN];  // {2^(j/256), 2^(-j/256)} interleaved: one 16-byte read serves both exponentials
   double l1[kWaveMaxTail + 6];  // log1p(-(j+0.5)/M), j < M  (host libm, psis.py:153,219-221)
   double bg[kWave];             // 1 - sqrt(m_est/(j+0.5)) for m_est(M)  (psis.py:186)
+#ifdef PLA_OCC_TEST
+  double dummy[PLA_OCC_TEST];
+#endif
 };
 
 // phase ablation for profiling (tools/ablate.sh); compiled out of the production kernel
