@@ -99,9 +99,6 @@ struct WaveSmem {
   double tab[2 * kTabN];  // {2^(j/256), 2^(-j/256)} interleaved: one 16-byte read serves both exponentials
   double l1[kWaveMaxTail + 6];  // log1p(-(j+0.5)/M), j < M  (host libm, psis.py:153,219-221)
   double bg[kWave];             // 1 - sqrt(m_est/(j+0.5)) for m_est(M)  (psis.py:186)
-#ifdef PLA_OCC_TEST
-  double dummy[PLA_OCC_TEST];
-#endif
 };
 
 // phase ablation for profiling (tools/ablate.sh); compiled out of the production kernel
@@ -172,7 +169,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       }
     }
   }
-  asm volatile("; MARK stats_begin");
   // ---- 1. row statistics, in the input precision (exact; duplicates of valid draws are harmless) ---
   // raw = -ll:  max raw = max(-v),  min raw = -max(v)
   double mx, mn, gmin;
@@ -194,7 +190,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     mn = -(double)vmx;
     gmin = (double)gmn;
   }
-  asm volatile("; MARK stats_end");
   const double m = wave_all<R_MAX>(mx);
   mn = wave_all<R_MIN>(mn);
   gmin = wave_all<R_MIN>(gmin);
@@ -209,7 +204,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   double khat = INF, loo = 0.0, lppd = 0.0;
   bool prefetched = false;
   if (!slow) {
-  asm volatile("; MARK setup_begin");
     // bins: (k - k1) >> sh  in [0, 1023] for k in [k1, 0]
     const int span = -k1;
     const int sh = (span >> 10) ? (32 - __builtin_clz((unsigned)(span >> 10))) : 0;
@@ -230,7 +224,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       }
     }
     __syncthreads();
-  asm volatile("; MARK sweep_begin");
     // ---- 2. sweep: e^x and e^-x of every draw from one range reduction + histogram of candidates ----
     // (e^(ll - max ll) = e^-R * e^-x; the row constant e^-R is applied to the sum, in log space)
     double s1 = 0.0, s2 = 0.0;
@@ -275,7 +268,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         if (!(dbgs & 2)) atomicAdd(&sm.hist[(k >= k1) ? ((k - k1) >> sh) : (kWaveBins + lane)], one);
       }
     }
-  asm volatile("; MARK sweep_end");
     {  // remove the pads' contribution (same code path, so it cancels to rounding)
       const double x = -R;
       const double t = fma(x, kC256, magic);
@@ -297,7 +289,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       loo = s1;
       lppd = s2;
     } else {
-  asm volatile("; MARK scan_begin");
       // ---- 3. suffix scan (16 bins per lane): start[b] = #draws in bins above b ---------------
       int bstar = 0, C1 = 0;
       {
@@ -341,7 +332,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       if (C1 > kWaveCap) {
         slow = true;
       } else {
-  asm volatile("; MARK scatter_begin");
         // ---- 4. candidates -> LDS grouped by bin (descending bins) -----------------------------
         const int kstar = k1 + (bstar << sh);
         // recompute x and its key from the row registers; the laundered copy of m keeps the compiler
@@ -359,7 +349,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           }
         }
         __syncthreads();
-  asm volatile("; MARK rank_begin");
         // ---- 5. exact descending rank inside each bin (ties: arbitrary, the sums do not care) --
         for (int c = lane; c < C1; c += kWave) {
           const double x = sm.sa[c];
@@ -374,7 +363,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           sm.sb[lo + cnt] = x;
         }
         __syncthreads();
-  asm volatile("; MARK cut_begin");
         // ---- cutoff (psis.py:135-141); R < 690: the log(DBL_MIN) floor cannot bind -------------
         const double xcut = sm.sb[M];
         int n = M;
@@ -396,7 +384,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           }
           __syncthreads();
           const double* yp = sm.sb;
-  asm volatile("; MARK fit_begin");
           // ---- 6. GPD fit (psis.py:163-208), lane j <-> grid point b_j -------------------------
           const int mest = 30 + isqrt_i(n);
           const double yq = y[((n + 2) >> 2) - 1];
@@ -412,7 +399,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           const bool wide = (fbig < 0x1p60) && (fsmall > 0x1p-60);
           // lanes whose b_j is ~0 would lose the low bits of b_j*y in 1 - b_j*y: carry them along
           const bool tiny = __ballot(act && fabs(b * yn) < 0.015625) != 0ull;
-  asm volatile("; MARK prod_begin");
           ProdAcc acc, acc2;
           acc.init();
           acc2.init();
@@ -443,7 +429,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
               acc.renorm();
             }
           }
-  asm volatile("; MARK prod_end");
           acc.m *= acc2.m;
           acc.e += acc2.e;
           const double rn = recip_fast(nn);
@@ -459,14 +444,12 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           const double sw = wave_all<R_SUM>(keep ? w : 0.0);
           const double bw = wave_all<R_SUM>(keep ? b * w : 0.0);
           const double b_post = (sw > 0.0) ? div_fast(bw, sw) : 0.0;                  // psis.py:198,201
-  asm volatile("; MARK kpost_begin");
           // psis.py:203: mean_i log1p(-b_post*y_i) as the log of per-lane products
           double pr = 1.0;
           for (int ii = lane; ii < n; ii += kWave) pr *= fma(-b_post, y[ii], 1.0);
           const double k_post = wave_all<R_SUM>(log_fast(pr)) * rn;
           const double sigma = -k_post / b_post;                                      // psis.py:205
           khat = (nn * k_post + 5.0) / (nn + 10.0);                                   // psis.py:206
-  asm volatile("; MARK smooth_begin");
           if (isfinite(khat)) {
             smoothed = true;
             const double rk = 1.0 / khat;
@@ -489,7 +472,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
             }
           }
         }
-  asm volatile("; MARK final_begin");
         // total = sum_nontail e^x + sum_tail w' = (s1 - sum_tail e) + sum_tail w'
         const double total = wave_all<R_SUM>(s1 + acc_t);
         s2 = wave_all<R_SUM>(s2);
