@@ -1,0 +1,49 @@
+"""A stand-in for ``pyloo_amd.engine.Engine`` backed by the CPU oracle.
+
+TEST INFRASTRUCTURE ONLY: it lets the CPU test-suite exercise the host-side Python of
+``pyloo_amd`` (argument handling, warnings, ``ELPDData`` packing, sharded reduction) without a
+GPU.  The product never uses it; GPU tests go through the real engine and the C ABI.
+"""
+
+import numpy as np
+
+from oracle import psis_oracle as orc
+from pyloo_amd._capi import AGG_COUNT
+
+
+class OracleEngine:
+    device = "cpu-oracle"
+
+    def psis_loo(self, ll, tail_count=0, method="psis", scale_value=1.0, good_k=0.7, pointwise=True, aggregate=True):
+        ll = np.asarray(ll, dtype=np.float64)
+        n, s = ll.shape
+        with np.errstate(all="ignore"):
+            if method == "psis":
+                lw = np.empty_like(ll)
+                diag = np.empty(n)
+                for i in range(n):
+                    lw[i], diag[i] = orc.psis_row(-ll[i], tail_count)
+            else:
+                lw, diag = orc.importance_weights(-ll, method)
+            loo_i = scale_value * np.array([orc.lse(r) for r in lw + ll], dtype=np.float64).reshape(n)
+            lppd_i = np.array([orc.lse(r, b_inv=s) for r in ll], dtype=np.float64).reshape(n)
+        agg = np.zeros(AGG_COUNT)
+        agg[0] = n
+        agg[1] = loo_i.sum()
+        agg[2] = np.sum((loo_i - loo_i.mean()) ** 2) if n else 0.0
+        agg[3] = lppd_i.sum()
+        agg[4] = np.sum(diag > good_k)
+        agg[5] = np.sum(~np.isfinite(diag))
+        agg[6] = diag.min() if n else np.inf
+        return {"diag": diag, "loo_i": loo_i, "lppd_i": lppd_i, "agg": agg}
+
+    def importance_weights(self, logw, tail_count=0, method="psis"):
+        logw = np.asarray(logw)
+        with np.errstate(all="ignore"):
+            if method == "psis":
+                lw = np.empty_like(logw)
+                diag = np.empty(logw.shape[0])
+                for i in range(logw.shape[0]):
+                    lw[i], diag[i] = orc.psis_row(logw[i], tail_count)
+                return lw, diag
+            return orc.importance_weights(logw, method)

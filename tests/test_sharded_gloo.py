@@ -1,0 +1,100 @@
+"""Observation sharding across ranks on CPU: two processes, ``gloo``.
+
+Every rank runs the per-observation pass on ITS OWN block of observations (here through the
+oracle-backed stand-in engine: no GPU in this suite) and the aggregates are merged with the one
+all-reduce of ``pyloo_amd.sharded``.  The merged numbers must equal the single-process result of
+the reference arithmetic on the whole matrix."""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import psis_oracle as orc
+from pyloo_amd.sharded import merge_moment_rows, shard_bounds
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 8, 1000, 1_000_003):
+        for w in (1, 2, 3, 8):
+            blocks = [shard_bounds(n, w, r) for r in range(w)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(b[1] == blocks[i + 1][0] for i, b in enumerate(blocks[:-1]))
+            sizes = [hi - lo for lo, hi in blocks]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_moment_merge_equals_numpy_var():
+    rng = np.random.default_rng(9)
+    x = rng.normal(-1e4, 0.1, size=10_000)  # |mean| >> sd: naive sum-of-squares would lose 1e-6
+    rows = []
+    for lo, hi in ((0, 10), (10, 10), (10, 4000), (4000, 10_000)):
+        c = x[lo:hi]
+        rows.append([c.size, c.sum(), np.sum((c - c.mean()) ** 2) if c.size else 0.0, c.sum() * 2, 1 if c.size else 0, 0, 0.5, 0])
+    out = merge_moment_rows(np.array(rows))
+    assert out[0] == x.size
+    np.testing.assert_allclose(out[1], x.sum(), rtol=1e-14)
+    np.testing.assert_allclose(out[2] / x.size, np.var(x), rtol=1e-10)
+    assert out[4] == 3 and out[6] == 0.5
+
+
+def _worker(rank, world, port, ll, reff, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    import warnings
+
+    import torch.distributed as dist
+
+    from fake_engine import OracleEngine
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng = OracleEngine()
+        importlib.import_module("pyloo_amd.loo").get_engine = lambda device=None: eng
+        import pyloo_amd as pl
+
+        lo, hi = shard_bounds(ll.shape[0], world, rank)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = pl.loo_from_matrix(ll[lo:hi], reff=reff, pointwise=True, distributed=True)
+        out_q.put((rank, {k: float(res[k]) for k in ("elpd_loo", "se", "p_loo", "p_loo_se", "looic", "looic_se")},
+                   int(res["n_data_points"]), bool(res["warning"]), np.asarray(res["loo_i"]).shape[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_obs", [37, 64])
+def test_two_ranks_match_single_process(n_obs):
+    import torch.multiprocessing as mp
+
+    rng = np.random.default_rng(n_obs)
+    k = rng.uniform(0.1, 1.0, size=n_obs)
+    ll = -k[:, None] * rng.exponential(size=(n_obs, 600)) - 2.0
+    reff = 0.8
+    want = orc.loo_arrays(ll, reff)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ll, reff, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sizes = 0
+    for rank, vals, n_total, warn, n_local in got:
+        assert n_total == n_obs and warn == (want["n_high_k"] > 0)
+        for key, v in vals.items():
+            np.testing.assert_allclose(v, want[key], rtol=1e-11, err_msg=f"rank {rank} {key}")
+        sizes += n_local
+    assert sizes == n_obs  # pointwise outputs stay sharded
