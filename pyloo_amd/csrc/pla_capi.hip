@@ -281,6 +281,7 @@ int pla_psis_loo(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int6
   p.tail_cap = pow2_at_least(p.tail_count);
   p.scale_value = scale_value;
   p.counters = eng->counters;
+  PLA_HIP(hipMemsetAsync(eng->counters, 0, 4 * sizeof(unsigned long long), s));  // [1]: rows left to the general kernel
   if (n_obs > 0) {
     rc = grow(&eng->d_slow, &eng->d_slow_bytes, (size_t)n_obs * sizeof(unsigned));
     if (rc) return rc;
@@ -315,7 +316,7 @@ int pla_psis_loo(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int6
       PLA_HIP(pla::launch_rows(p, dtype, false, s));
     }
     if (agg) {
-      pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, agg, eng->counters};
+      pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, agg, eng->counters + 1};
       PLA_HIP(pla::launch_reduce(rp, eng->d_red, s));
     }
     return PLA_OK;
@@ -369,7 +370,7 @@ int pla_psis_loo(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int6
     if (lppd_i) PLA_HIP(hipMemcpyAsync(lppd_i, dp, n_obs * sizeof(double), hipMemcpyDeviceToHost, s));
   }
   if (agg) {
-    pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, dagg, nullptr};
+    pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, dagg, eng->counters + 1};
     PLA_HIP(pla::launch_reduce(rp, eng->d_red, s));
     PLA_HIP(hipMemcpyAsync(agg, dagg, PLA_AGG_COUNT * sizeof(double), hipMemcpyDeviceToHost, s));
   }

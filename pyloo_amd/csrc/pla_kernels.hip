@@ -47,6 +47,7 @@ __global__ __launch_bounds__(BLOCK) void slow_rows_kernel(RowsParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const Smem sm = carve<BLOCK>(smem_raw, P.tail_cap);
   const unsigned long long count = P.counters[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&P.counters[1], count);  // running total of this call
   for (unsigned long long i = blockIdx.x; i < count; i += gridDim.x) {
     const int64_t r = (int64_t)P.slow_list[i];
     const T* rp = reinterpret_cast<const T*>(P.in) + r * P.stride_obs;
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(kWave) void reduce_stage2(ReduceParams P, const dou
   P.agg[PLA_AGG_N_HIGH] = n_high;
   P.agg[PLA_AGG_N_NONFINITE] = n_bad;
   P.agg[PLA_AGG_MIN_DIAG] = dmin;
-  P.agg[PLA_AGG_N_SLOW] = P.counters ? (double)P.counters[0] : 0.0;
+  P.agg[PLA_AGG_N_SLOW] = P.counters ? (double)P.counters[0] : 0.0;  // caller passes &counters[1]
 }
 
 template <typename T>

@@ -4,6 +4,8 @@ the real reference and against the CPU oracle on seeded inputs.  Run with ``-m g
 Tolerance: north_star asks for 1e-6 relative on fp64 inputs; the engine is held to RTOL
 below (three orders tighter) with an absolute floor ATOL for quantities that pass through 0."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -12,6 +14,7 @@ from conftest import load_golden
 from oracle import psis_oracle as orc
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 RTOL = 1e-9
 ATOL = 1e-10
@@ -240,3 +243,95 @@ def test_loo_front_matches_reference_numbers(eng):
     close(np.asarray(res["pareto_k"]), g["khat"], what="pareto_k")
     close(np.asarray(res["loo_i"]), g["loo_i"], what="loo_i")
     assert "Pareto k diagnostic values" in str(res)
+
+
+def test_fast_and_slow_rows_in_one_matrix(eng):
+    """Rows the wave kernel must hand to the general kernel (non-finite entries, > 690 nats of range,
+    degenerate thresholds) mixed into ordinary rows: every row equals the oracle, and the hand-over
+    count is what it should be."""
+    rng = np.random.default_rng(2024)
+    N, S = 300, 4000
+    k = rng.uniform(0.05, 1.3, size=N)
+    ll = -k[:, None] * rng.exponential(size=(N, S)) - 1.0
+    special = {
+        3: "nan", 17: "pinf", 40: "ninf", 77: "wide", 101: "const", 150: "two_values", 222: "outlier", 260: "grid",
+    }
+    ll[3, 5] = np.nan
+    ll[17, 9] = np.inf
+    ll[40, 11] = -np.inf
+    ll[77] *= 400.0                      # range far above 690 nats: the log(DBL_MIN) floor binds
+    ll[101] = -2.5                       # constant row: empty tail, k = inf
+    ll[150] = np.where(np.arange(S) % 2 == 0, -1.0, -3.0)   # two distinct values: ties everywhere
+    ll[222, 7] = -5000.0                 # one draw 5000 nats below the rest
+    ll[260] = -np.round(ll[260] * -4.0) / 4.0                # coarse grid: ties inside the tail
+    ref = orc.loo_arrays(ll, 1.0)
+    res = eng.psis_loo(ll, 190, "psis", 1.0, 0.7)
+    close(res["diag"], ref["khat"], what="khat")
+    close(res["loo_i"], ref["loo_i"], what="loo_i")
+    close(res["lppd_i"], ref["lppd_i"], what="lppd_i")
+    n_slow = int(res["agg"][7])
+    assert 5 <= n_slow <= 16, n_slow     # nan, pinf, ninf, wide, const, outlier (+ possibly tie rows)
+    assert int(res["agg"][5]) == int(np.sum(~np.isfinite(ref["khat"])))
+
+
+def test_general_kernel_agrees_with_fast_path():
+    """Same matrix through the wave kernel and (in a child process) through the general kernel only."""
+    import subprocess
+    import sys
+    import tempfile
+
+    rng = np.random.default_rng(77)
+    ll = -rng.uniform(0.1, 1.1, size=(200, 1)) * rng.exponential(size=(200, 2048)) - 0.5
+    from pyloo_amd.engine import get_engine
+
+    fast = get_engine(0).psis_loo(ll, 136, "psis", 1.0, 0.7)
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "ll.npy"), ll)
+        code = (
+            "import sys, numpy as np; sys.path.insert(0, %r); from pyloo_amd.engine import get_engine;"
+            "ll = np.load(%r); r = get_engine(0).psis_loo(ll, 136, 'psis', 1.0, 0.7);"
+            "np.savez(%r, diag=r['diag'], loo_i=r['loo_i'], lppd_i=r['lppd_i'], agg=r['agg'])"
+        ) % (ROOT, os.path.join(d, "ll.npy"), os.path.join(d, "out.npz"))
+        env = dict(os.environ, PLA_FORCE_PATH="1")
+        subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
+        gen = np.load(os.path.join(d, "out.npz"))
+        assert fast["agg"][7] == 0 and gen["agg"][7] == 0
+        for key in ("diag", "loo_i", "lppd_i"):
+            close(fast[key], gen[key], what=key)
+        np.testing.assert_allclose(fast["agg"][1:4], gen["agg"][1:4], rtol=1e-10)
+
+
+def test_full_size_properties(eng):
+    """BASELINE config C2 size (S=4000 x N=100k, device-generated): determinism, reductions,
+    oracle parity on a strided sample, and the smoothed weights' normalisation."""
+    import torch
+
+    S, N = 4000, 100_000
+    t = torch.empty((N, S), dtype=torch.float64, device="cuda")
+    eng.fill_synthetic(t, seed=0x5EED0002)
+    a = eng.psis_loo(t, 190, "psis", 1.0, 0.7)
+    b = eng.psis_loo(t, 190, "psis", 1.0, 0.7)
+    torch.cuda.synchronize()
+    for key in ("diag", "loo_i", "lppd_i", "agg"):
+        assert torch.equal(a[key], b[key]), key          # bitwise reproducible
+    loo_i, lppd_i, diag = (a[k].cpu().numpy() for k in ("loo_i", "lppd_i", "diag"))
+    agg = a["agg"].cpu().numpy()
+    assert np.all(np.isfinite(loo_i)) and np.all(np.isfinite(lppd_i)) and np.all(np.isfinite(diag))
+    assert np.all(loo_i <= lppd_i + 1e-9)                 # leave-one-out density never beats the in-sample one
+    import math
+
+    np.testing.assert_allclose(agg[1], math.fsum(loo_i), rtol=1e-12)
+    np.testing.assert_allclose(agg[3], math.fsum(lppd_i), rtol=1e-12)
+    np.testing.assert_allclose(agg[2] / N, np.var(loo_i), rtol=1e-9)
+    assert agg[0] == N and agg[4] == np.sum(diag > 0.7) and agg[7] == 0
+    again = eng.reduce_pointwise(a["diag"], a["loo_i"], a["lppd_i"], 0.7).cpu().numpy()
+    assert np.array_equal(again[:7], agg[:7])
+    idx = np.arange(0, N, 997)                            # 101 rows against the oracle
+    ref = orc.loo_arrays(t[idx].cpu().numpy(), 1.0)
+    close(diag[idx], ref["khat"], what="khat sample")
+    close(loo_i[idx], ref["loo_i"], what="loo_i sample")
+    close(lppd_i[idx], ref["lppd_i"], what="lppd_i sample")
+    lw, kk = eng.importance_weights(-t[:2048], 190)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(torch.exp(lw).sum(dim=1).cpu().numpy(), 1.0, rtol=1e-12)
+    close(kk.cpu().numpy(), diag[:2048], what="khat (weights pass)")
