@@ -14,7 +14,8 @@ __device__ __forceinline__ double red_apply(double a, double b) {
   else return fmin(a, b);
 }
 struct FastParams {
-  int gsz;                        // slots per threshold group (informational; compile-time in the kernel)
+  int gsz;                        // register slots per lane whose maximum feeds the speculative threshold
+  int kq;                         // the threshold has >= kq of the 64 per-lane maxima below it
   unsigned* slow_list;            // [n_obs] rows for the general kernel
   unsigned long long* counters;   // [0] = number of rows in slow_list
   int debug_skip;                 // phase-ablation bits, honoured only by PLA_WAVE_ABLATE builds

@@ -169,15 +169,25 @@ static hipError_t launch_one(const RowsParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-static int wave_groups(int S, int vec, int gsz) {
-  int g = 0;
-  for (int lane = 0; lane < kWave; ++lane)
-    for (int i = 0; i < kWaveSlots; i += gsz) {
-      const int il = i + gsz - 1;  // last slot of the group: groups must be made of real draws only
-      const int s = vec * (lane + kWave * (il / vec)) + (il % vec);
-      if (s < S) ++g;
-    }
-  return g;
+// Speculative threshold of the wave kernel: the kq-th smallest (roughly) of the 64 per-lane maxima
+// over the first gsz register slots.  For exchangeable draws a draw lies below it with probability F,
+// F^gsz = kq/64.  Pick (gsz, kq) so that ~2.6(M+1) draws lie above, with kq large enough for the order
+// statistic to be stable.  Returns false when no setting fits (the general kernel takes the call).
+static bool wave_threshold_params(int S, int vec, int M, int* gsz_out, int* kq_out) {
+  const double target = 2.6 * (M + 1);
+  if (target > 0.62 * kCandCap || target >= 0.5 * S) return false;
+  const double F = 1.0 - target / S;
+  const int valid = (S / vec / kWave) * vec;  // slots that are real draws in every lane
+  int best_g = 0, best_k = 0;
+  for (int g = 4; g <= 32; g <<= 1) {
+    if (g > valid) break;
+    const int k = (int)std::lround(kWave * std::pow(F, g));
+    if (k >= 6 && k <= 40 && (best_g == 0 || k > best_k)) { best_g = g; best_k = k; }
+  }
+  if (!best_g) return false;
+  *gsz_out = best_g;
+  *kq_out = best_k;
+  return true;
 }
 
 static int debug_flag(const char* name) {
@@ -185,9 +195,8 @@ static int debug_flag(const char* name) {
   return v ? atoi(v) : 0;
 }
 
-template <typename T, int VEC, int GSZ>
-static hipError_t launch_wave(const RowsParams& p, hipStream_t stream) {
-  const int gsz = GSZ;
+template <typename T, int VEC>
+static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   static const int dbg = debug_flag("PLA_DEBUG_SKIP");
@@ -195,11 +204,11 @@ static hipError_t launch_wave(const RowsParams& p, hipStream_t stream) {
   while (root_ * root_ > p.tail_count) --root_;
   while ((root_ + 1) * (root_ + 1) <= p.tail_count) ++root_;
   const int mestM = 30 + root_;
-  FastParams f{gsz, p.slow_list, p.counters, dbg, p.l1_table, std::log((double)p.n_draws), p.l1_table + p.tail_count, mestM};
+  FastParams f{gsz, kq, p.slow_list, p.counters, dbg, p.l1_table, std::log((double)p.n_draws), p.l1_table + p.tail_count, mestM};
   // one wave per workgroup; 8 x 2048 workgroups keep all 256 CUs (8 waves each) busy with a short tail
   int64_t grid = p.n_obs;
   if (grid > 2048 * 8) grid = 2048 * 8;
-  hipLaunchKernelGGL((wave_loo_kernel<T, VEC, GSZ>), dim3((unsigned)grid), dim3(kWave), 0, stream, p, f);
+  hipLaunchKernelGGL((wave_loo_kernel<T, VEC>), dim3((unsigned)grid), dim3(kWave), 0, stream, p, f);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   // general kernel over whatever the fast path declined (usually nothing)
@@ -221,9 +230,8 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream) {
     if (path != 1 && unit && waligned && p.method == PLA_PSIS && p.slow_list && p.counters && p.l1_table &&
         p.n_draws <= kWave * kWaveSlots && p.n_draws >= 256 && p.tail_count <= kWaveMaxTail &&
         smem_bytes(BLOCK, p.tail_cap) <= 64 * 1024 && p.n_obs <= 0xffffffffll) {
-      // threshold groups of 16 or 8 register slots (compile-time); enough groups guarantee >= M+1 candidates
-      if (wave_groups(p.n_draws, WVEC, 16) >= p.tail_count + 1) return launch_wave<T, WVEC, 16>(p, stream);
-      if (wave_groups(p.n_draws, WVEC, 8) >= p.tail_count + 1) return launch_wave<T, WVEC, 8>(p, stream);
+      int gsz = 0, kq = 0;
+      if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq)) return launch_wave<T, WVEC>(p, gsz, kq, stream);
     }
     if (path == 1) return launch_one<T, BLOCK, 0, LW>(p, stream);
   }

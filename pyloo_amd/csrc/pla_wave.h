@@ -36,7 +36,8 @@
 namespace pla {
 
 constexpr int kWaveSlots = 64;   // register slots per lane -> S <= 4096
-constexpr int kWaveBins = 1024;
+constexpr int kWaveBins = 512;   // histogram bins over the candidate list
+constexpr int kCandCap = 896;    // candidates (draws above the speculative threshold) kept in LDS
 constexpr int kWaveCap = 320;    // candidates kept in LDS; needs M + boundary-bin extras
 constexpr int kWaveMaxTail = 250;
 constexpr double kWaveMaxRange = 690.0;  // nats: e^x, e^-x and their sums over 4096 draws stay finite and normal
@@ -58,6 +59,12 @@ __device__ __forceinline__ double lane_value(double v, int lane) {  // wave-unif
 }
 
 __device__ __forceinline__ double uniform_d(double v) { return lane_value(v, 0); }
+
+// One wavefront per workgroup: LDS operations of a wave are processed in order, so handing data
+// between lanes through LDS needs no s_barrier -- and must not use __syncthreads(), whose fence
+// drains the vector-memory queue (vmcnt(0)) and with it the next row's loads already in flight.
+// The compiler only has to keep the LDS accesses in program order.
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
 // max without the canonicalising self-max the compiler adds around fmax (NaNs are detected
 // separately with v_cmp_class); NEG folds the sign flip of the first operand into the instruction
@@ -92,13 +99,14 @@ __device__ __forceinline__ double wave_all(double v) {
 }
 
 struct WaveSmem {
-  unsigned hist[kWaveBins + kWave];  // + one private dummy bin per lane for draws below the threshold
-  unsigned short start[kWaveBins];  // #draws in bins above b (<= 4096)
-  double sa[kWaveCap];
-  double sb[kWaveCap];
-  double tab[2 * kTabN];  // {2^(j/256), 2^(-j/256)} interleaved: one 16-byte read serves both exponentials
-  double l1[kWaveMaxTail + 6];  // log1p(-(j+0.5)/M), j < M  (host libm, psis.py:153,219-221)
-  double bg[kWave];             // 1 - sqrt(m_est/(j+0.5)) for m_est(M)  (psis.py:186)
+  unsigned hist[kWaveBins];
+  unsigned short start[kWaveBins];  // #candidates in bins above b
+  double cand[kCandCap + kWave];    // candidate x values in sweep order (+ one dump slot per lane);
+                                    // reused for the candidates sorted descending once they are binned
+  double sa[kWaveCap];              // candidates at/above the boundary bin, grouped by bin; later y ascending
+  double tab[2 * kTabN];            // {2^(j/256), 2^(-j/256)} interleaved: one 16-byte read serves both exponentials
+  double l1[kWaveMaxTail + 6];      // log1p(-(j+0.5)/M), j < M  (host libm, psis.py:153,219-221)
+  double bg[kWave];                 // 1 - sqrt(m_est/(j+0.5)) for m_est(M)  (psis.py:186)
 };
 
 // phase ablation for profiling (tools/ablate.sh); compiled out of the production kernel
@@ -134,7 +142,7 @@ __device__ __forceinline__ void issue_row_loads(T (&v)[kWaveSlots], const T* rp,
   }
 }
 
-template <typename T, int VEC, int GSZ>
+template <typename T, int VEC>
 __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParams& F, WaveSmem& sm, const int64_t r,
                                             T (&v)[kWaveSlots], const T* rp_next) {
   constexpr int EPT = kWaveSlots;
@@ -143,6 +151,8 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   // parameters arrive by reference (memory): read each once into scalar registers
   const int S = __builtin_amdgcn_readfirstlane(P.n_draws);
   const int M = __builtin_amdgcn_readfirstlane(P.tail_count);
+  const int gsz = __builtin_amdgcn_readfirstlane(F.gsz);
+  const int kq = __builtin_amdgcn_readfirstlane(F.kq);
 #if PLA_WAVE_ABLATE
   const int dbgs = __builtin_amdgcn_readfirstlane(F.debug_skip);
 #else
@@ -170,31 +180,39 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     }
   }
   // ---- 1. row statistics, in the input precision (exact; duplicates of valid draws are harmless) ---
-  // raw = -ll:  max raw = max(-v),  min raw = -max(v)
-  double mx, mn, gmin;
+  // raw = -ll:  max raw = max(-v),  min raw = -max(v);  gs = max raw over this lane's first `gsz` slots
+  double mx, mn, gs;
   {
     const T ninf = (T)(-INF);
-    T gcur = ninf, vmx = ninf, gmx = ninf, gmn = (T)INF;
+    T cur = ninf, vmx = ninf, snap = ninf;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
-      gcur = vmax_nc<true>(v[i], gcur);
+      cur = vmax_nc<true>(v[i], cur);
       vmx = vmax_nc<false>(v[i], vmx);
-      if (((i + 1) & (GSZ - 1)) == 0) {  // compile-time: the loop is fully unrolled
-        // a group made only of pads repeats this lane's first draws: it can only lower gmin
-        gmn = -vmax_nc<true>(gcur, -gmn);  // min(gmn, gcur)
-        gmx = vmax_nc<false>(gcur, gmx);
-        gcur = ninf;
-      }
+      if (i == gsz - 1) snap = cur;  // wave-uniform
     }
-    mx = (double)gmx;
+    mx = (double)cur;
     mn = -(double)vmx;
-    gmin = (double)gmn;
+    gs = (double)snap;
   }
   const double m = wave_all<R_MAX>(mx);
   mn = wave_all<R_MIN>(mn);
-  gmin = wave_all<R_MIN>(gmin);
   const double R = m - mn;
-  const double t1 = gmin - m;
+  // Speculative candidate threshold: a value with at least `kq` of the 64 per-lane group maxima
+  // below it, found by bisection on ballots.  For exchangeable draws a fraction ~(kq/64)^(1/gsz) of
+  // the row lies below it, i.e. a few hundred draws lie above (the launcher picks gsz and kq so that
+  // this is ~3(M+1)); rows where the guess is off are recomputed by the general kernel.
+  double t1;
+  {
+    double lo = wave_all<R_MIN>(gs), hi = m;
+#pragma unroll 1
+    for (int it = 0; it < 12; ++it) {
+      const double mid = 0.5 * (lo + hi);
+      const int below = __popcll(__ballot(gs < mid));
+      if (below >= kq) hi = mid; else lo = mid;
+    }
+    t1 = hi - m;
+  }
   // +-inf in the row makes R inf/NaN; a NaN draw is ignored by v_max here, poisons s1 in the sweep
   // and is caught by the finiteness test at the end: both land on the general kernel
   bool slow = !(R < kWaveMaxRange) || !(t1 < 0.0);
@@ -204,10 +222,10 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   double khat = INF, loo = 0.0, lppd = 0.0;
   bool prefetched = false;
   if (!slow) {
-    // bins: (k - k1) >> sh  in [0, 1023] for k in [k1, 0]
+    // bins over the candidates: (k - k1) >> sh  in [0, 511] for k in [k1, 0]
     const int span = -k1;
-    const int sh = (span >> 10) ? (32 - __builtin_clz((unsigned)(span >> 10))) : 0;
-    __syncthreads();  // previous row is done with the histogram
+    const int sh = (span >> 9) ? (32 - __builtin_clz((unsigned)(span >> 9))) : 0;
+    wave_sync();  // previous row is done with the LDS scratch
     {
       const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
@@ -223,14 +241,14 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         for (int e = 0; e < VEC; ++e) v[q * VEC + e] = ok ? v[q * VEC + e] : padv;
       }
     }
-    __syncthreads();
+    wave_sync();
     // ---- 2. sweep: e^x and e^-x of every draw from one range reduction + histogram of candidates ----
     // (e^(ll - max ll) = e^-R * e^-x; the row constant e^-R is applied to the sum, in log space)
     double s1 = 0.0, s2 = 0.0;
     const double* tab = sm.tab;
     double magic = kMagic;
-    unsigned one = 1u;
-    asm volatile("" : "+v"(magic), "+v"(one));  // keep both resident instead of re-materialising per draw
+    asm volatile("" : "+v"(magic));  // keep it resident instead of re-materialising per draw
+    unsigned ncand = 0;            // wave-uniform
     // Software pipeline, kPF draws deep: stage A of draw i+kPF (shift, range reduction, table read,
     // histogram count) is issued before stage B of draw i (polynomial, accumulate), so the LDS
     // latency of the table read is covered by the arithmetic of the draws in between.
@@ -264,8 +282,15 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         px[sl] = x;
         pt[sl] = t;
         ptt[sl] = *reinterpret_cast<const double2*>(tab + 2 * (k & 255));
-        // branch-free: draws below the threshold count into the lane's own dummy bin
-        if (!(dbgs & 2)) atomicAdd(&sm.hist[(k >= k1) ? ((k - k1) >> sh) : (kWaveBins + lane)], one);
+        // candidates (k >= k1) are appended to the LDS list.  One wave owns the list, so the slot is
+        // a running scalar count + the rank of the lane among the candidates of this draw (no atomics);
+        // everybody else writes to the lane's private dump slot, which keeps the sweep branch-free.
+        const bool cand = k >= k1;
+        const unsigned long long cm = __ballot(cand);
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
+        const unsigned pos = cand ? (ncand + rank) : (unsigned)(kCandCap + lane);
+        sm.cand[pos < (unsigned)(kCandCap + kWave) ? pos : (unsigned)(kCandCap + lane)] = x;
+        ncand += (unsigned)__popcll(cm);
       }
     }
     {  // remove the pads' contribution (same code path, so it cancels to rounding)
@@ -284,19 +309,27 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         s2 = fma(-npad * add_hi(tt.y, -es), fma(-rr, O, E), s2);
       }
     }
-    __syncthreads();
+    // the row registers are dead from here on: start streaming the next row into them now, so its
+    // HBM latency is covered by the selection / fit / smoothing work below
+    if (rp_next) issue_row_loads<T, VEC>(v, rp_next, S);
+    prefetched = true;
+    wave_sync();
     if (dbgs & 4) {
       loo = s1;
       lppd = s2;
+    } else if ((int)ncand < M + 1 || ncand > (unsigned)kCandCap) {
+      slow = true;  // the speculative threshold missed (too few / too many draws above it)
     } else {
-      // ---- 3. suffix scan (16 bins per lane): start[b] = #draws in bins above b ---------------
+      // ---- 3. histogram of the candidate list, suffix scan (8 bins per lane) ---------------------
+      for (unsigned c = lane; c < ncand; c += kWave) atomicAdd(&sm.hist[(key256(sm.cand[c]) - k1) >> sh], 1u);
+      wave_sync();
       int bstar = 0, C1 = 0;
       {
-        unsigned c[16];
+        unsigned c[8];
         unsigned tot = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint4 h = *reinterpret_cast<const uint4*>(&sm.hist[16 * lane + 4 * i]);
+        for (int i = 0; i < 2; ++i) {
+          const uint4 h = *reinterpret_cast<const uint4*>(&sm.hist[8 * lane + 4 * i]);
           c[4 * i] = h.x; c[4 * i + 1] = h.y; c[4 * i + 2] = h.z; c[4 * i + 3] = h.w;
           tot += h.x + h.y + h.z + h.w;
         }
@@ -306,49 +339,42 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           const unsigned t = (unsigned)__shfl_down((int)suf, o);
           if (lane + o < kWave) suf += t;
         }
-        unsigned a = suf - tot;  // draws in bins owned by higher lanes
+        unsigned a = suf - tot;  // candidates in bins owned by higher lanes
         int fb = -1, fc = 0;
-        unsigned st[16];
+        unsigned st[8];
 #pragma unroll
-        for (int i = 15; i >= 0; --i) {
+        for (int i = 7; i >= 0; --i) {
           st[i] = a;
           if ((unsigned)M >= a && (unsigned)M < a + c[i]) {
-            fb = 16 * lane + i;
+            fb = 8 * lane + i;
             fc = (int)(a + c[i]);
           }
           a += c[i];
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          *reinterpret_cast<uint4*>(&sm.start[16 * lane + 8 * i]) =
-              make_uint4(st[8 * i] | (st[8 * i + 1] << 16), st[8 * i + 2] | (st[8 * i + 3] << 16),
-                         st[8 * i + 4] | (st[8 * i + 5] << 16), st[8 * i + 6] | (st[8 * i + 7] << 16));
+        *reinterpret_cast<uint4*>(&sm.start[8 * lane]) =
+            make_uint4(st[0] | (st[1] << 16), st[2] | (st[3] << 16), st[4] | (st[5] << 16), st[6] | (st[7] << 16));
         const unsigned long long who = __ballot(fb >= 0);
         const int src = __ffsll((long long)who) - 1;
         bstar = __builtin_amdgcn_readlane(fb, src);
         C1 = __builtin_amdgcn_readlane(fc, src);
       }
-      __syncthreads();
+      wave_sync();
       if (C1 > kWaveCap) {
         slow = true;
       } else {
-        // ---- 4. candidates -> LDS grouped by bin (descending bins) -----------------------------
+        // ---- 4. candidates at/above the boundary bin -> sa, grouped by bin (descending bins) --------
         const int kstar = k1 + (bstar << sh);
-        // recompute x and its key from the row registers; the laundered copy of m keeps the compiler
-        // from carrying 64 live x values over from the sweep (they would spill)
-        double m2 = m;
-        asm volatile("" : "+s"(m2));
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-          const double x = (-(double)v[i]) - m2;
-          const int k = __double2loint(fma(x, kC256, magic));
+        for (unsigned c = lane; c < ncand; c += kWave) {
+          const double x = sm.cand[c];
+          const int k = key256(x);
           if (k >= kstar) {
             const int b = (k - k1) >> sh;
             const unsigned slot = sm.start[b] + (atomicSub(&sm.hist[b], 1u) - 1u);
             sm.sa[slot] = x;
           }
         }
-        __syncthreads();
+        wave_sync();
+        double* sb = sm.cand;  // the list is consumed: its storage now holds the sorted candidates
         // ---- 5. exact descending rank inside each bin (ties: arbitrary, the sums do not care) --
         for (int c = lane; c < C1; c += kWave) {
           const double x = sm.sa[c];
@@ -360,30 +386,30 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
             const double x2 = sm.sa[c2];
             cnt += (x2 > x || (x2 == x && c2 > c)) ? 1 : 0;
           }
-          sm.sb[lo + cnt] = x;
+          sb[lo + cnt] = x;
         }
-        __syncthreads();
+        wave_sync();
         // ---- cutoff (psis.py:135-141); R < 690: the log(DBL_MIN) floor cannot bind -------------
-        const double xcut = sm.sb[M];
+        const double xcut = sb[M];
         int n = M;
-        while (n > 0 && sm.sb[n - 1] == xcut) --n;  // ties at the cutoff leave the tail
+        while (n > 0 && sb[n - 1] == xcut) --n;  // ties at the cutoff leave the tail
         const double e_cut = exp_tab(xcut, sm.tab);
         double acc_t = 0.0, acc_r = 0.0;  // (sum w' - sum e) and sum w'/e over the tail
         bool smoothed = false;
         if (n > 4 && !(dbgs & 8)) {
-          __syncthreads();
+          wave_sync();
           // y ascending (psis.py:146-147), stored with the pair sums / products the fit loop eats
-          for (int j = lane; j < n; j += kWave) sm.sa[j] = exp_tab(sm.sb[n - 1 - j], sm.tab) - e_cut;
-          __syncthreads();
+          for (int j = lane; j < n; j += kWave) sm.sa[j] = exp_tab(sb[n - 1 - j], sm.tab) - e_cut;
+          wave_sync();
           const double* y = sm.sa;
           const double nn = (double)n;
           // (1 - b y0)(1 - b y1) = 1 - b (y0 + y1) + b^2 y0 y1: pair sums / products once per row
           for (int p2 = lane; 2 * p2 + 1 < n; p2 += kWave) {
             const double2 yy = *reinterpret_cast<const double2*>(y + 2 * p2);
-            *reinterpret_cast<double2*>(&sm.sb[2 * p2]) = make_double2(yy.x + yy.y, yy.x * yy.y);
+            *reinterpret_cast<double2*>(&sb[2 * p2]) = make_double2(yy.x + yy.y, yy.x * yy.y);
           }
-          __syncthreads();
-          const double* yp = sm.sb;
+          wave_sync();
+          const double* yp = sb;
           // ---- 6. GPD fit (psis.py:163-208), lane j <-> grid point b_j -------------------------
           const int mest = 30 + isqrt_i(n);
           const double yq = y[((n + 2) >> 2) - 1];
@@ -500,7 +526,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
 // The per-row body is deliberately NOT inlined into the row loop: inlined, LLVM hoists every
 // loop-invariant constant, mask and offset of the later phases above the loop, where they sit on
 // top of the 128 row registers and spill.
-template <typename T, int VEC, int GSZ>
+template <typename T, int VEC>
 __global__ __launch_bounds__(kWave, 2) void wave_loo_kernel(RowsParams P, FastParams F) {
   __shared__ __attribute__((aligned(16))) WaveSmem sm;
   const int lane = threadIdx.x;
@@ -512,13 +538,13 @@ __global__ __launch_bounds__(kWave, 2) void wave_loo_kernel(RowsParams P, FastPa
   }
   for (int j = lane; j < P.tail_count; j += kWave) sm.l1[j] = F.l1_table[j];
   sm.bg[lane] = F.b_grid[lane];
-  __syncthreads();
+  wave_sync();
   T v[kWaveSlots];
   const T* base = reinterpret_cast<const T*>(P.in);
   if ((int64_t)blockIdx.x < P.n_obs) issue_row_loads<T, VEC>(v, base + (int64_t)blockIdx.x * P.stride_obs, P.n_draws);
   for (int64_t r = blockIdx.x; r < P.n_obs; r += gridDim.x) {
     const int64_t rn = r + gridDim.x;
-    wave_loo_row<T, VEC, GSZ>(P, F, sm, r, v, rn < P.n_obs ? base + rn * P.stride_obs : nullptr);
+    wave_loo_row<T, VEC>(P, F, sm, r, v, rn < P.n_obs ? base + rn * P.stride_obs : nullptr);
   }
 }
 

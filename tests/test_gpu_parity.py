@@ -323,7 +323,8 @@ def test_full_size_properties(eng):
     np.testing.assert_allclose(agg[1], math.fsum(loo_i), rtol=1e-12)
     np.testing.assert_allclose(agg[3], math.fsum(lppd_i), rtol=1e-12)
     np.testing.assert_allclose(agg[2] / N, np.var(loo_i), rtol=1e-9)
-    assert agg[0] == N and agg[4] == np.sum(diag > 0.7) and agg[7] == 0
+    assert agg[0] == N and agg[4] == np.sum(diag > 0.7)
+    assert agg[7] <= 0.002 * N                            # rows where the speculative threshold missed
     again = eng.reduce_pointwise(a["diag"], a["loo_i"], a["lppd_i"], 0.7).cpu().numpy()
     assert np.array_equal(again[:7], agg[:7])
     idx = np.arange(0, N, 997)                            # 101 rows against the oracle
