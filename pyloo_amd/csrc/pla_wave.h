@@ -220,7 +220,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   const int kpad = key256(-R);               // key of the pad value (smallest x of the row)
   if (kpad >= k1) slow = true;               // pads would be counted as candidates
   double khat = INF, loo = 0.0, lppd = 0.0;
-  bool prefetched = false;
   if (!slow) {
     // bins over the candidates: (k - k1) >> sh  in [0, 511] for k in [k1, 0]
     const int span = -k1;
@@ -309,10 +308,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         s2 = fma(-npad * add_hi(tt.y, -es), fma(-rr, O, E), s2);
       }
     }
-    // the row registers are dead from here on: start streaming the next row into them now, so its
-    // HBM latency is covered by the selection / fit / smoothing work below
-    if (rp_next) issue_row_loads<T, VEC>(v, rp_next, S);
-    prefetched = true;
     wave_sync();
     if (dbgs & 4) {
       loo = s1;
@@ -510,7 +505,9 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       }
     }
   }
-  if (!prefetched && rp_next) issue_row_loads<T, VEC>(v, rp_next, S);
+  // the next row starts streaming into the (now dead) row registers while the outputs are stored and
+  // the other wave of this SIMD computes
+  if (rp_next) issue_row_loads<T, VEC>(v, rp_next, S);
   if (lane == 0) {
     if (slow) {
       const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
