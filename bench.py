@@ -27,6 +27,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def measured_traffic(n_obs, n_draws, dtype):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (tools/profile.sh ->
+    profiles/traffic_latest.json: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), or None
+    when no profile of this exact workload is committed."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("obs") == n_obs and t.get("draws") == n_draws and t.get("dtype") == dtype:
+            return t["hbm_read_bytes"] + t["hbm_write_bytes"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,7 +158,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": measured_traffic(n_local, S, args.dtype),
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes,
         },
@@ -156,10 +171,11 @@ def main():
         chunk = 512
         done, t_cpu = 0, 0.0
         worst = {"khat": 0.0, "loo_i": 0.0, "lppd_i": 0.0}
-        full = eng.psis_loo(ll[: min(n_local, 65536)], M, "psis", 1.0, good_k)
+        cap = min(n_local, 262144)
+        full = eng.psis_loo(ll[:cap], M, "psis", 1.0, good_k)
         torch.cuda.synchronize()
         gk, gl, gp = (full[k].cpu().numpy() for k in ("diag", "loo_i", "lppd_i"))
-        while t_cpu < args.cpu_seconds and done + chunk <= min(n_local, 65536):
+        while t_cpu < args.cpu_seconds and done + chunk <= cap:
             rows = ll[done:done + chunk].cpu().numpy().astype(np.float64)
             c0 = time.perf_counter()
             ref = orc.loo_pointwise(rows, reff)
