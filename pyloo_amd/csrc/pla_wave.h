@@ -101,8 +101,8 @@ __device__ __forceinline__ double wave_all(double v) {
 struct WaveSmem {
   unsigned hist[kWaveBins];
   unsigned short start[kWaveBins];  // #candidates in bins above b
-  double cand[kCandCap + kWave];    // candidate x values in sweep order (+ one dump slot per lane);
-                                    // reused for the candidates sorted descending once they are binned
+  double cand[kCandCap + kWave];    // candidate x values (+ one dump slot per lane); reused for the
+                                    // candidates sorted descending once they are binned
   double sa[kWaveCap];              // candidates at/above the boundary bin, grouped by bin; later y ascending
   double tab[2 * kTabN];            // {2^(j/256), 2^(-j/256)} interleaved: one 16-byte read serves both exponentials
   double l1[kWaveMaxTail + 6];      // log1p(-(j+0.5)/M), j < M  (host libm, psis.py:153,219-221)
@@ -142,6 +142,20 @@ __device__ __forceinline__ void issue_row_loads(T (&v)[kWaveSlots], const T* rp,
   }
 }
 
+// one 16-byte vector (slots q*VEC .. q*VEC+VEC-1) of a row
+template <typename T, int VEC>
+__device__ __forceinline__ void issue_row_vector(T (&v)[kWaveSlots], const __amdgpu_buffer_rsrc_t rs, int q) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const v4i t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)threadIdx.x * 16, q * (kWave * 16), 2 /* nt */);
+  if constexpr (VEC == 2) {
+    v[2 * q] = (T)__hiloint2double(t[1], t[0]);
+    v[2 * q + 1] = (T)__hiloint2double(t[3], t[2]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[4 * q + e] = (T)__int_as_float(t[e]);
+  }
+}
+
 template <typename T, int VEC>
 __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParams& F, WaveSmem& sm, const int64_t r,
                                             T (&v)[kWaveSlots], const T* rp_next) {
@@ -172,7 +186,8 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     // slots past the row: copy this lane's first vector (harmless for max / min / threshold)
 #pragma unroll
     for (int q = 1; q < NQ; ++q) {
-      if (q >= qfull) {  // wave-uniform
+      if (q >= qfull) {  // wave-uniform; keep it a branch (not 2*NQ selects): usually one vector is partial
+        asm volatile("");
         const bool ok = (q == qfull) && (lane < qrem);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) v[q * VEC + e] = ok ? v[q * VEC + e] : v[e];
@@ -220,6 +235,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   const int kpad = key256(-R);               // key of the pad value (smallest x of the row)
   if (kpad >= k1) slow = true;               // pads would be counted as candidates
   double khat = INF, loo = 0.0, lppd = 0.0;
+  bool streamed = false;  // next row's loads already issued (inside the sweep)
   if (!slow) {
     // bins over the candidates: (k - k1) >> sh  in [0, 511] for k in [k1, 0]
     const int span = -k1;
@@ -234,7 +250,8 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     const T padv = (T)(-mn);
 #pragma unroll
     for (int q = 1; q < NQ; ++q) {
-      if (q >= qfull) {  // uniform
+      if (q >= qfull) {  // uniform branch, see above
+        asm volatile("");
         const bool ok = (q == qfull && lane < qrem);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) v[q * VEC + e] = ok ? v[q * VEC + e] : padv;
@@ -247,7 +264,15 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     const double* tab = sm.tab;
     double magic = kMagic;
     asm volatile("" : "+v"(magic));  // keep it resident instead of re-materialising per draw
-    unsigned ncand = 0;            // wave-uniform
+    // the four fp64 constants of the sweep live in SGPR pairs for its whole length (with MachineLICM
+    // off the compiler would re-materialise each of them with two s_mov per use)
+    double c256 = kC256, nl256 = -kLn2_256, c24 = 4.16666666666666666667e-02, c6 = 1.66666666666666666667e-01;
+    asm volatile("" : "+s"(c256), "+s"(nl256), "+s"(c24), "+s"(c6));
+    unsigned ncand = 0;                                  // wave-uniform
+    const __amdgpu_buffer_rsrc_t rs_next =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(rp_next ? rp_next : (const T*)P.in), 0, S * (int)sizeof(T), 0x00020000);
+    streamed = true;
+    const unsigned dumpi = (unsigned)(kCandCap + lane);  // this lane's dump slot
     // Software pipeline, kPF draws deep: stage A of draw i+kPF (shift, range reduction, table read,
     // histogram count) is issued before stage B of draw i (polynomial, accumulate), so the LDS
     // latency of the table read is covered by the arithmetic of the draws in between.
@@ -260,10 +285,10 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         const int sl = (i - kPF) % kPF;
         const double x = px[sl], t = pt[sl];
         const int k = __double2loint(t);
-        const double rr = fma(t - magic, -kLn2_256, x);
+        const double rr = fma(t - magic, nl256, x);
         const double r2 = rr * rr;
-        const double E = fma(fma(4.16666666666666666667e-02, r2, 0.5), r2, 1.0);
-        const double O = fma(1.66666666666666666667e-01, r2, 1.0);
+        const double E = fma(fma(c24, r2, 0.5), r2, 1.0);
+        const double O = fma(c6, r2, 1.0);
         const int es = (k << 12) & 0xfff00000;  // (k >> 8) << 20: 2^(k >> 8) goes into the table entry
         if (!(dbgs & 1)) {
           s1 = fma(add_hi(ptt[sl].x, es), fma(rr, O, E), s1);
@@ -276,20 +301,26 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       if (i < EPT) {  // stage A of draw i
         const int sl = i % kPF;
         const double x = (-(double)v[i]) - m;  // psis.py:134
-        const double t = fma(x, kC256, magic);
+        const double t = fma(x, c256, magic);
         const int k = __double2loint(t);       // round(x * 256/ln2): low mantissa bits of t
         px[sl] = x;
         pt[sl] = t;
         ptt[sl] = *reinterpret_cast<const double2*>(tab + 2 * (k & 255));
-        // candidates (k >= k1) are appended to the LDS list.  One wave owns the list, so the slot is
-        // a running scalar count + the rank of the lane among the candidates of this draw (no atomics);
-        // everybody else writes to the lane's private dump slot, which keeps the sweep branch-free.
-        const bool cand = k >= k1;
+        // candidates (x >= t1, ~1 draw in 7) are appended to the LDS list.  One wave owns the list, so
+        // the slot is a running scalar count + the lane's rank among this draw's candidates: no
+        // atomic, no LDS round trip.  Everybody else (and any overflow) writes to the lane's private
+        // dump slot, which keeps the sweep free of branches.
+        const bool cand = x >= t1;
         const unsigned long long cm = __ballot(cand);
         const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
-        const unsigned pos = cand ? (ncand + rank) : (unsigned)(kCandCap + lane);
-        sm.cand[pos < (unsigned)(kCandCap + kWave) ? pos : (unsigned)(kCandCap + lane)] = x;
+        const unsigned pos = cand ? (ncand + rank) : dumpi;
+        sm.cand[pos < dumpi ? pos : dumpi] = x;
         ncand += (unsigned)__popcll(cm);
+        // This was the last read of slot i.  Once a whole 16-byte vector has been consumed, the next
+        // row's vector is streamed into the same registers: the loads of row r+1 trickle out during
+        // the sweep of row r and have the whole selection / fit / smoothing phase to arrive, without a
+        // single extra register and without a burst that would stall every wave of the CU at once.
+        if ((i % VEC) == VEC - 1 && rp_next) issue_row_vector<T, VEC>(v, rs_next, i / VEC);
       }
     }
     {  // remove the pads' contribution (same code path, so it cancels to rounding)
@@ -417,7 +448,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           const double b_first = lane_value(b, 0);  // most negative grid point
           const double b_last = uniform_d(__shfl(b, mest - 1));
           const double fbig = fma(-b_first, yn, 1.0), fsmall = fma(-b_last, yn, 1.0);
-          const bool wide = (fbig < 0x1p60) && (fsmall > 0x1p-60);
+          const bool wide = (fbig < 0x1p30) && (fsmall > 0x1p-30);  // 16 factors per accumulator between renorms
           // lanes whose b_j is ~0 would lose the low bits of b_j*y in 1 - b_j*y: carry them along
           const bool tiny = __ballot(act && fabs(b * yn) < 0.015625) != 0ull;
           ProdAcc acc, acc2;
@@ -427,18 +458,24 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           double corr = 0.0;
           int i = 0;
           if (wide && !tiny) {
-            for (; i + 8 <= n; i += 8) {
-              const double2 pa = *reinterpret_cast<const double2*>(yp + i);
-              const double2 pb = *reinterpret_cast<const double2*>(yp + i + 2);
-              const double2 pc = *reinterpret_cast<const double2*>(yp + i + 4);
-              const double2 pd = *reinterpret_cast<const double2*>(yp + i + 6);
-              acc.mul(fma(nb, fma(nb, pa.y, pa.x), 1.0));
-              acc2.mul(fma(nb, fma(nb, pb.y, pb.x), 1.0));
-              acc.mul(fma(nb, fma(nb, pc.y, pc.x), 1.0));
-              acc2.mul(fma(nb, fma(nb, pd.y, pd.x), 1.0));
+            for (; i + 32 <= n; i += 32) {
+#pragma unroll
+              for (int u = 0; u < 32; u += 4) {
+                const double2 pa = *reinterpret_cast<const double2*>(yp + i + u);
+                const double2 pb = *reinterpret_cast<const double2*>(yp + i + u + 2);
+                acc.mul(fma(nb, fma(nb, pa.y, pa.x), 1.0));
+                acc2.mul(fma(nb, fma(nb, pb.y, pb.x), 1.0));
+              }
               acc.renorm();
               acc2.renorm();
             }
+            for (; i + 4 <= n; i += 4) {
+              const double2 pa = *reinterpret_cast<const double2*>(yp + i);
+              const double2 pb = *reinterpret_cast<const double2*>(yp + i + 2);
+              acc.mul(fma(nb, fma(nb, pa.y, pa.x), 1.0));
+              acc2.mul(fma(nb, fma(nb, pb.y, pb.x), 1.0));
+            }
+            acc2.renorm();
             for (; i < n; ++i) acc.mul(fma(nb, y[i], 1.0));
             acc.renorm();
           } else {
@@ -507,7 +544,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   }
   // the next row starts streaming into the (now dead) row registers while the outputs are stored and
   // the other wave of this SIMD computes
-  if (rp_next) issue_row_loads<T, VEC>(v, rp_next, S);
+  if (!streamed && rp_next) issue_row_loads<T, VEC>(v, rp_next, S);  // rows that never reached the sweep
   if (lane == 0) {
     if (slow) {
       const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
