@@ -17,7 +17,6 @@
 
 #include "pla_fast.h"
 #include "pla_rows.h"
-#include "pla_team.h"
 #include "pla_wave.h"
 
 namespace pla {
@@ -220,33 +219,12 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, hipStream_t 
   return hipGetLastError();
 }
 
-template <typename T, int VEC>
-static hipError_t launch_team(const RowsParams& p, int gsz, int kq, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
-  if (e != hipSuccess) return e;
-  int root_ = (int)std::sqrt((double)p.tail_count);
-  while (root_ * root_ > p.tail_count) --root_;
-  while ((root_ + 1) * (root_ + 1) <= p.tail_count) ++root_;
-  FastParams f{gsz, kq, p.slow_list, p.counters, 0, p.l1_table, std::log((double)p.n_draws), p.l1_table + p.tail_count, 30 + root_};
-  // two waves per observation, 8 workgroups (16 waves) resident per CU
-  int64_t grid = p.n_obs;
-  if (grid > 2048 * 8) grid = 2048 * 8;
-  hipLaunchKernelGGL((team_loo_kernel<T, VEC>), dim3((unsigned)grid), dim3(kTeamBlock), 0, stream, p, f);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  constexpr int BLOCK = 256;
-  int64_t g2 = p.n_obs < 1024 ? p.n_obs : 1024;
-  hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap),
-                     stream, p);
-  return hipGetLastError();
-}
-
 template <typename T, bool LW>
 static hipError_t launch_typed(const RowsParams& p, hipStream_t stream) {
   constexpr int BLOCK = 256;
   const bool unit = (p.stride_draw == 1);
   if constexpr (!LW) {
-    static const int path = debug_flag("PLA_FORCE_PATH");  // 0 auto, 1 general kernel only, 4 two-waves-per-row variant (experiments)
+    static const int path = debug_flag("PLA_FORCE_PATH");  // 0 auto, 1 general kernel only (tests)
     constexpr int WVEC = 16 / sizeof(T);
     const bool waligned = ((uintptr_t)p.in % 16 == 0) && (p.stride_obs % WVEC == 0) && (p.n_draws % WVEC == 0);
     if (path != 1 && unit && waligned && p.method == PLA_PSIS && p.slow_list && p.counters && p.l1_table &&
@@ -254,9 +232,6 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream) {
         smem_bytes(BLOCK, p.tail_cap) <= 64 * 1024 && p.n_obs <= 0xffffffffll) {
       int gsz = 0, kq = 0;
       if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq)) {
-        // the team kernel keeps 32 slots per thread: the threshold group must consist of real draws
-        const int team_valid = (p.n_draws / WVEC / kTeamBlock) * WVEC;
-        if (path == 4 && gsz <= team_valid) return launch_team<T, WVEC>(p, gsz, kq, stream);
         return launch_wave<T, WVEC>(p, gsz, kq, stream);
       }
     }

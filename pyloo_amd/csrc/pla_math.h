@@ -38,14 +38,22 @@ __device__ __forceinline__ double scale_exp(double v, int es) {  // v * 2^(es >>
   b += (long long)es << 32;
   return __longlong_as_double(b);
 }
-// e^x for x in [-700, 709] from a table with tab[2*j] = 2^(j/256) (entries 16 bytes apart)
+// The table: entry j (16 bytes) = {2^(j/256), 2^(-j/256)} with the high words biased by -/+ (j << 12).
+// With k = 256 e + j the scaled entry 2^e * 2^(j/256) is then  hi + (k << 12)  -- one integer
+// multiply-add, no masking of k -- and likewise  hi - (k << 12)  for 2^-e * 2^(-j/256).
+__device__ __forceinline__ void exp_table_entry(double* tab, int j) {
+  const double p = exp2((double)j * (1.0 / kTabN)), n = exp2(-(double)j * (1.0 / kTabN));
+  tab[2 * j] = __hiloint2double(__double2hiint(p) - (j << 12), __double2loint(p));
+  tab[2 * j + 1] = __hiloint2double(__double2hiint(n) + (j << 12), __double2loint(n));
+}
+// e^x for x in [-700, 709]; results must stay normal
 __device__ __forceinline__ double exp_tab(double x, const double* tab) {
   const Red256 q = reduce256(x);
   const double tj = tab[2 * (q.k & 255)];
   const double r2 = q.r * q.r;
   const double E = fma(fma(4.16666666666666666667e-02, r2, 0.5), r2, 1.0);
   const double O = fma(1.66666666666666666667e-01, r2, 1.0);
-  return scale_exp(tj * fma(q.r, O, E), (q.k >> 8) << 20);
+  return __hiloint2double(__double2hiint(tj) + (q.k << 12), __double2loint(tj)) * fma(q.r, O, E);
 }
 // e^x for any x <= 0 (and NaN -> caller's problem): clamps where e^x underflows anyway
 __device__ __forceinline__ double exp_neg(double x, const double* tab) { return exp_tab(fmax(x, -700.0), tab); }

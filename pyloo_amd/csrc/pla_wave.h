@@ -101,7 +101,7 @@ __device__ __forceinline__ double wave_all(double v) {
 struct WaveSmem {
   unsigned hist[kWaveBins];
   unsigned short start[kWaveBins];  // #candidates in bins above b
-  double cand[kCandCap + kWave];    // candidate x values (+ one dump slot per lane); reused for the
+  double cand[kCandCap + 2 * kWave];  // candidate x values (+ 64 overflow slots + one dump slot per lane); reused for the
                                     // candidates sorted descending once they are binned
   double sa[kWaveCap];              // candidates at/above the boundary bin, grouped by bin; later y ascending
   double tab[2 * kTabN];            // {2^(j/256), 2^(-j/256)} interleaved: one 16-byte read serves both exponentials
@@ -113,9 +113,26 @@ struct WaveSmem {
 #ifndef PLA_WAVE_ABLATE
 #define PLA_WAVE_ABLATE 0
 #endif
+// phase markers in the ISA for tools/isa_stats.py (comments only; off in the production build)
+#if defined(PLA_PHASE_MARKS)
+#define PLA_PHASE_STR2(n) #n
+#define PLA_PHASE(n) asm volatile("; PLA_PHASE " PLA_PHASE_STR2(n))
+#else
+#define PLA_PHASE(n) ((void)0)
+#endif
 
-__device__ __forceinline__ double add_hi(double v, int d) {  // v * 2^(d >> 20) for normal v and result
-  return __hiloint2double(__double2hiint(v) + d, __double2loint(v));
+// a * b + c on the low 24 bits of a and b (one VALU op; b is a scalar register)
+__device__ __forceinline__ int mad_i24(int a, int b, int c) {
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+  return d;
+}
+// (k & 255) << sh in one VALU op (SDWA byte select); sh lives in a VGPR
+__device__ __forceinline__ unsigned byte0_shl(int k, int sh) {
+  unsigned d;
+  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0"
+      : "=v"(d) : "v"(sh), "v"(k));
+  return d;
 }
 
 // Issue the 16-byte buffer loads of one row into the register slots (slot q*VEC+e holds draw
@@ -156,6 +173,23 @@ __device__ __forceinline__ void issue_row_vector(T (&v)[kWaveSlots], const __amd
   }
 }
 
+// Overwrite the slots of vectors q >= qfull that lie past the end of the row (lanes >= qrem of
+// vector qfull, every lane of the later ones) with `padv` (CONST) or with the lane's first vector.
+// Written as a recursion from the last vector down so that it compiles to a chain of wave-uniform
+// early exits (usually one vector is partial) rather than NQ predicated selects.
+template <typename T, int VEC, int Q, bool CONST>
+__device__ __forceinline__ void pad_tail(T (&v)[kWaveSlots], int qfull, int qrem, T padv) {
+  if constexpr (Q >= 1) {
+    if (Q >= qfull) {
+      asm volatile("");  // keep the branch
+      const bool ok = (Q == qfull) && ((int)threadIdx.x < qrem);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[Q * VEC + e] = ok ? v[Q * VEC + e] : (CONST ? padv : v[e]);
+      pad_tail<T, VEC, Q - 1, CONST>(v, qfull, qrem, padv);
+    }
+  }
+}
+
 template <typename T, int VEC>
 __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParams& F, WaveSmem& sm, const int64_t r,
                                             T (&v)[kWaveSlots], const T* rp_next) {
@@ -184,15 +218,9 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   // ---- finish the load issued by the previous iteration (or the prologue): pad fix-up -------------
   {
     // slots past the row: copy this lane's first vector (harmless for max / min / threshold)
-#pragma unroll
-    for (int q = 1; q < NQ; ++q) {
-      if (q >= qfull) {  // wave-uniform; keep it a branch (not 2*NQ selects): usually one vector is partial
-        asm volatile("");
-        const bool ok = (q == qfull) && (lane < qrem);
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) v[q * VEC + e] = ok ? v[q * VEC + e] : v[e];
-      }
-    }
+    // (from the last vector down, leaving at the first complete one: a chain of wave-uniform early
+    // exits instead of NQ predicated selects -- usually a single vector is partial)
+    pad_tail<T, VEC, NQ - 1, false>(v, qfull, qrem, (T)0);
   }
   // ---- 1. row statistics, in the input precision (exact; duplicates of valid draws are harmless) ---
   // raw = -ll:  max raw = max(-v),  min raw = -max(v);  gs = max raw over this lane's first `gsz` slots
@@ -204,7 +232,12 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     for (int i = 0; i < EPT; ++i) {
       cur = vmax_nc<true>(v[i], cur);
       vmx = vmax_nc<false>(v[i], vmx);
-      if (i == gsz - 1) snap = cur;  // wave-uniform
+      if (i == 3 || i == 7 || i == 15 || i == 31) {  // gsz is one of 4, 8, 16, 32 (wave_threshold_params)
+        if (gsz == i + 1) {
+          asm volatile("");  // a real wave-uniform branch, not a select per slot
+          snap = cur;
+        }
+      }
     }
     mx = (double)cur;
     mn = -(double)vmx;
@@ -230,6 +263,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   }
   // +-inf in the row makes R inf/NaN; a NaN draw is ignored by v_max here, poisons s1 in the sweep
   // and is caught by the finiteness test at the end: both land on the general kernel
+  PLA_PHASE(1);
   bool slow = !(R < kWaveMaxRange) || !(t1 < 0.0);
   const int k1 = key256(t1);                 // histogram origin
   const int kpad = key256(-R);               // key of the pad value (smallest x of the row)
@@ -248,95 +282,96 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     }
     // pads: rewrite invalid vectors to ll = -mn  (raw = mn, x = -R)
     const T padv = (T)(-mn);
-#pragma unroll
-    for (int q = 1; q < NQ; ++q) {
-      if (q >= qfull) {  // uniform branch, see above
-        asm volatile("");
-        const bool ok = (q == qfull && lane < qrem);
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) v[q * VEC + e] = ok ? v[q * VEC + e] : padv;
-      }
-    }
+    pad_tail<T, VEC, NQ - 1, true>(v, qfull, qrem, padv);
     wave_sync();
     // ---- 2. sweep: e^x and e^-x of every draw from one range reduction + histogram of candidates ----
     // (e^(ll - max ll) = e^-R * e^-x; the row constant e^-R is applied to the sum, in log space)
+    PLA_PHASE(2);
     double s1 = 0.0, s2 = 0.0;
-    const double* tab = sm.tab;
     double magic = kMagic;
     asm volatile("" : "+v"(magic));  // keep it resident instead of re-materialising per draw
-    // the four fp64 constants of the sweep live in SGPR pairs for its whole length (with MachineLICM
-    // off the compiler would re-materialise each of them with two s_mov per use)
-    double c256 = kC256, nl256 = -kLn2_256, c24 = 4.16666666666666666667e-02, c6 = 1.66666666666666666667e-01;
-    asm volatile("" : "+s"(c256), "+s"(nl256), "+s"(c24), "+s"(c6));
-    unsigned ncand = 0;                                  // wave-uniform
-    const __amdgpu_buffer_rsrc_t rs_next =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(rp_next ? rp_next : (const T*)P.in), 0, S * (int)sizeof(T), 0x00020000);
+    // the constants of the sweep live in SGPRs for its whole length (with MachineLICM off the compiler
+    // would re-materialise each of them with s_mov per use)
+    double c256 = kC256, nl256 = -kLn2_256, c6 = 1.66666666666666666667e-01;
+    int c4096 = 4096, cm4096 = -4096;
+    asm volatile("" : "+s"(c256), "+s"(nl256), "+s"(c6), "+s"(c4096), "+s"(cm4096));
+    int four = 4;
+    asm volatile("" : "+v"(four));
+    unsigned ncand8 = 0;                                 // 8 * candidates so far (wave-uniform)
+    // the next row (a zero-length range when there is none: the loads then return zeros and touch nothing)
+    const __amdgpu_buffer_rsrc_t rs_next = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(rp_next ? rp_next : (const T*)P.in), 0, rp_next ? S * (int)sizeof(T) : 0, 0x00020000);
     streamed = true;
-    const unsigned dumpi = (unsigned)(kCandCap + lane);  // this lane's dump slot
+    const char* tabc = reinterpret_cast<const char*>(sm.tab);
+    char* candc = reinterpret_cast<char*>(sm.cand);
+    const unsigned dump8 = (unsigned)(kCandCap + kWave + lane) * 8u;  // this lane's dump slot
+    unsigned base8 = 0;                                   // 8 * min(ncand, kCandCap): byte offset of the next append
     // Software pipeline, kPF draws deep: stage A of draw i+kPF (shift, range reduction, table read,
-    // histogram count) is issued before stage B of draw i (polynomial, accumulate), so the LDS
+    // candidate append) is issued before stage B of draw i (polynomial, accumulate), so the LDS
     // latency of the table read is covered by the arithmetic of the draws in between.
     constexpr int kPF = 3;
     double px[kPF], pt[kPF];
-    double2 ptt[kPF];
+    int4 ptt[kPF];
 #pragma unroll
     for (int i = 0; i < EPT + kPF; ++i) {
-      if (i >= kPF) {  // stage B of draw i - kPF
+      if (i >= kPF) {  // stage B of draw i - kPF: 11 VALU
         const int sl = (i - kPF) % kPF;
         const double x = px[sl], t = pt[sl];
         const int k = __double2loint(t);
-        const double rr = fma(t - magic, nl256, x);
+        const double rr = fma(t - magic, nl256, x);        // |rr| <= ln2/512
         const double r2 = rr * rr;
-        const double E = fma(fma(c24, r2, 0.5), r2, 1.0);
-        const double O = fma(c6, r2, 1.0);
-        const int es = (k << 12) & 0xfff00000;  // (k >> 8) << 20: 2^(k >> 8) goes into the table entry
+        const double E = fma(r2, 0.5, 1.0);                // cosh rr to 1.5e-13 (r^4/24 dropped)
+        const double O = fma(c6, r2, 1.0);                 // sinh rr / rr
         if (!(dbgs & 1)) {
-          s1 = fma(add_hi(ptt[sl].x, es), fma(rr, O, E), s1);
-          s2 = fma(add_hi(ptt[sl].y, -es), fma(-rr, O, E), s2);
+          s1 = fma(__hiloint2double(mad_i24(k, c4096, ptt[sl].y), ptt[sl].x), fma(rr, O, E), s1);
+          s2 = fma(__hiloint2double(mad_i24(k, cm4096, ptt[sl].w), ptt[sl].z), fma(-rr, O, E), s2);
         }
         // pin the running sums: otherwise the accumulation chain is sunk to the end of the block and
         // its inputs (table entries, reduced arguments) spill
         if ((i & 3) == 3) asm volatile("" : "+v"(s1), "+v"(s2));
       }
-      if (i < EPT) {  // stage A of draw i
+      if (i < EPT) {  // stage A of draw i: 8 VALU
         const int sl = i % kPF;
         const double x = (-(double)v[i]) - m;  // psis.py:134
         const double t = fma(x, c256, magic);
         const int k = __double2loint(t);       // round(x * 256/ln2): low mantissa bits of t
         px[sl] = x;
         pt[sl] = t;
-        ptt[sl] = *reinterpret_cast<const double2*>(tab + 2 * (k & 255));
+        ptt[sl] = *reinterpret_cast<const int4*>(tabc + byte0_shl(k, four));  // 16 * (k & 255)
         // candidates (x >= t1, ~1 draw in 7) are appended to the LDS list.  One wave owns the list, so
         // the slot is a running scalar count + the lane's rank among this draw's candidates: no
-        // atomic, no LDS round trip.  Everybody else (and any overflow) writes to the lane's private
-        // dump slot, which keeps the sweep free of branches.
+        // atomic, no LDS round trip.  Everybody else writes to the lane's private dump slot, which
+        // keeps the sweep free of branches; an overflowing list spills into the 64 slots behind it.
         const bool cand = x >= t1;
         const unsigned long long cm = __ballot(cand);
         const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
-        const unsigned pos = cand ? (ncand + rank) : dumpi;
-        sm.cand[pos < dumpi ? pos : dumpi] = x;
-        ncand += (unsigned)__popcll(cm);
+        unsigned pos8 = (rank << 3) + base8;
+        asm("" : "+v"(pos8));  // computed by every lane: a select below, not a divergent region
+        *reinterpret_cast<double*>(candc + (cand ? pos8 : dump8)) = x;
+        ncand8 += (unsigned)__popcll(cm) << 3;
+        base8 = ncand8 < (unsigned)(8 * kCandCap) ? ncand8 : (unsigned)(8 * kCandCap);
         // This was the last read of slot i.  Once a whole 16-byte vector has been consumed, the next
         // row's vector is streamed into the same registers: the loads of row r+1 trickle out during
         // the sweep of row r and have the whole selection / fit / smoothing phase to arrive, without a
         // single extra register and without a burst that would stall every wave of the CU at once.
-        if ((i % VEC) == VEC - 1 && rp_next) issue_row_vector<T, VEC>(v, rs_next, i / VEC);
+        if ((i % VEC) == VEC - 1) issue_row_vector<T, VEC>(v, rs_next, i / VEC);
       }
     }
+    const unsigned ncand = ncand8 >> 3;
+    PLA_PHASE(3);
     {  // remove the pads' contribution (same code path, so it cancels to rounding)
       const double x = -R;
       const double t = fma(x, kC256, magic);
       const int k = __double2loint(t);
       const double rr = fma(t - magic, -kLn2_256, x);
-      const double2 tt = *reinterpret_cast<const double2*>(tab + 2 * (k & 255));
+      const int4 tt = *reinterpret_cast<const int4*>(tabc + 16 * (k & 255));
       const double r2 = rr * rr;
-      const double E = fma(fma(4.16666666666666666667e-02, r2, 0.5), r2, 1.0);
+      const double E = fma(r2, 0.5, 1.0);
       const double O = fma(1.66666666666666666667e-01, r2, 1.0);
-      const int es = (k << 12) & 0xfff00000;
       const double npad = (double)((NQ - qfull) * VEC - ((lane < qrem) ? VEC : 0));  // padded slots of this lane
       if (!(dbgs & 1)) {
-        s1 = fma(-npad * add_hi(tt.x, es), fma(rr, O, E), s1);
-        s2 = fma(-npad * add_hi(tt.y, -es), fma(-rr, O, E), s2);
+        s1 = fma(-npad * __hiloint2double(tt.y + (k << 12), tt.x), fma(rr, O, E), s1);
+        s2 = fma(-npad * __hiloint2double(tt.w - (k << 12), tt.z), fma(-rr, O, E), s2);
       }
     }
     wave_sync();
@@ -347,8 +382,10 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       slow = true;  // the speculative threshold missed (too few / too many draws above it)
     } else {
       // ---- 3. histogram of the candidate list, suffix scan (8 bins per lane) ---------------------
+      PLA_PHASE(4);
       for (unsigned c = lane; c < ncand; c += kWave) atomicAdd(&sm.hist[(key256(sm.cand[c]) - k1) >> sh], 1u);
       wave_sync();
+      PLA_PHASE(5);
       int bstar = 0, C1 = 0;
       {
         unsigned c[8];
@@ -389,6 +426,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         slow = true;
       } else {
         // ---- 4. candidates at/above the boundary bin -> sa, grouped by bin (descending bins) --------
+        PLA_PHASE(6);
         const int kstar = k1 + (bstar << sh);
         for (unsigned c = lane; c < ncand; c += kWave) {
           const double x = sm.cand[c];
@@ -400,6 +438,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           }
         }
         wave_sync();
+        PLA_PHASE(7);
         double* sb = sm.cand;  // the list is consumed: its storage now holds the sorted candidates
         // ---- 5. exact descending rank inside each bin (ties: arbitrary, the sums do not care) --
         for (int c = lane; c < C1; c += kWave) {
@@ -416,6 +455,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         }
         wave_sync();
         // ---- cutoff (psis.py:135-141); R < 690: the log(DBL_MIN) floor cannot bind -------------
+        PLA_PHASE(8);
         const double xcut = sb[M];
         int n = M;
         while (n > 0 && sb[n - 1] == xcut) --n;  // ties at the cutoff leave the tail
@@ -437,6 +477,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           wave_sync();
           const double* yp = sb;
           // ---- 6. GPD fit (psis.py:163-208), lane j <-> grid point b_j -------------------------
+          PLA_PHASE(9);
           const int mest = 30 + isqrt_i(n);
           const double yq = y[((n + 2) >> 2) - 1];
           const double yn = y[n - 1];
@@ -451,6 +492,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           const bool wide = (fbig < 0x1p30) && (fsmall > 0x1p-30);  // 16 factors per accumulator between renorms
           // lanes whose b_j is ~0 would lose the low bits of b_j*y in 1 - b_j*y: carry them along
           const bool tiny = __ballot(act && fabs(b * yn) < 0.015625) != 0ull;
+          PLA_PHASE(10);
           ProdAcc acc, acc2;
           acc.init();
           acc2.init();
@@ -487,6 +529,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
               acc.renorm();
             }
           }
+          PLA_PHASE(11);
           acc.m *= acc2.m;
           acc.e += acc2.e;
           const double rn = recip_fast(nn);
@@ -503,11 +546,13 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           const double bw = wave_all<R_SUM>(keep ? b * w : 0.0);
           const double b_post = (sw > 0.0) ? div_fast(bw, sw) : 0.0;                  // psis.py:198,201
           // psis.py:203: mean_i log1p(-b_post*y_i) as the log of per-lane products
+          PLA_PHASE(12);
           double pr = 1.0;
           for (int ii = lane; ii < n; ii += kWave) pr *= fma(-b_post, y[ii], 1.0);
           const double k_post = wave_all<R_SUM>(log_fast(pr)) * rn;
           const double sigma = -k_post / b_post;                                      // psis.py:205
           khat = (nn * k_post + 5.0) / (nn + 10.0);                                   // psis.py:206
+          PLA_PHASE(13);
           if (isfinite(khat)) {
             smoothed = true;
             const double rk = 1.0 / khat;
@@ -531,6 +576,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           }
         }
         // total = sum_nontail e^x + sum_tail w' = (s1 - sum_tail e) + sum_tail w'
+        PLA_PHASE(14);
         const double total = wave_all<R_SUM>(s1 + acc_t);
         s2 = wave_all<R_SUM>(s2);
         // loo_i = -m - L + log(tail_ratio),  L = log(total) (psis.py:158; loo.py:289,319-324): one log
@@ -544,6 +590,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   }
   // the next row starts streaming into the (now dead) row registers while the outputs are stored and
   // the other wave of this SIMD computes
+  PLA_PHASE(15);
   if (!streamed && rp_next) issue_row_loads<T, VEC>(v, rp_next, S);  // rows that never reached the sweep
   if (lane == 0) {
     if (slow) {
@@ -567,8 +614,7 @@ __global__ __launch_bounds__(kWave, 2) void wave_loo_kernel(RowsParams P, FastPa
 #pragma unroll
   for (int i = 0; i < kTabN / kWave; ++i) {
     const int j = lane + kWave * i;
-    sm.tab[2 * j] = exp2((double)j * (1.0 / kTabN));
-    sm.tab[2 * j + 1] = exp2(-(double)j * (1.0 / kTabN));
+    exp_table_entry(sm.tab, j);
   }
   for (int j = lane; j < P.tail_count; j += kWave) sm.l1[j] = F.l1_table[j];
   sm.bg[lane] = F.b_grid[lane];

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Static instruction mix of one kernel in the gfx950 ISA of pla_kernels.hip (no GPU needed).
+
+usage: python tools/isa_stats.py [kernel-name-substring] [extra hipcc flags...]
+Prints VALU / SALU / LDS / VMEM counts, SGPR-spill traffic (v_writelane / v_readlane), scratch
+traffic, and the register budget the compiler reports.  If the source carries
+`asm volatile("; PLA_PHASE n")` markers the counts are also split by phase.
+"""
+import collections
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    pat = sys.argv[1] if len(sys.argv) > 1 else "wave_loo_kernelIdLi2"
+    extra = sys.argv[2:]
+    out = "/tmp/pla_isa.s"
+    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-disable-machine-licm",
+           "--offload-device-only", "-S", "-o", out, os.path.join(ROOT, "pyloo_amd/csrc/pla_kernels.hip")] + extra
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    lines = open(out).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + re.escape(pat) + r"\w*:", l))
+    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+    total = collections.Counter()
+    phases = collections.defaultdict(collections.Counter)
+    ph = 0
+    for l in lines[start:end]:
+        l = l.strip()
+        m = re.match(r"; PLA_PHASE (\d+)", l)
+        if m:
+            ph = int(m.group(1))
+            continue
+        if not l or l[0] in ";." or l.endswith(":"):
+            continue
+        op = l.split()[0]
+        kind = "VALU" if op.startswith("v_") else "SALU" if op.startswith("s_") else "LDS" if op.startswith("ds_") else "VMEM"
+        for c in (total, phases[ph]):
+            c[kind] += 1
+            if op in ("v_writelane_b32", "v_readlane_b32", "s_nop", "s_waitcnt") or op.startswith("scratch_"):
+                c[op] += 1
+            if op.startswith("s_cbranch") or op == "s_branch":
+                c["branch"] += 1
+    print(lines[start].split(":")[0])
+    print(" total", dict(total))
+    if len(phases) > 1:
+        for k in sorted(phases):
+            print(f"  phase {k:2d}", dict(phases[k]))
+    for l in lines[end:end + 80]:
+        if re.search(r"\.(vgpr_count|sgpr_count|private_segment_fixed_size|sgpr_spill_count|vgpr_spill_count)", l) or \
+           re.search(r"; (NumVgprs|NumAgprs|ScratchSize|Occupancy|LDSByteSize|SGPRSpill|NumSgprs)", l):
+            print(" ", l.strip())
+
+
+if __name__ == "__main__":
+    main()

@@ -6,7 +6,7 @@ LIB=$ROOT/pyloo_amd/lib/libpyloo_amd_ablate.so
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -disable-machine-licm -DPLA_WAVE_ABLATE=1 -fPIC -shared \
     -o "$LIB" "$ROOT/pyloo_amd/csrc/pla_kernels.hip" "$ROOT/pyloo_amd/csrc/pla_capi.hip"
 cd /tmp && export TMPDIR=/tmp
-for sk in 0 1 4 5 7 8; do
+for sk in ${SKIPS:-0 1 4 5 7 8}; do
   rm -rf /tmp/pi_$sk
   PYLOO_AMD_LIB=$LIB PLA_DEBUG_SKIP=$sk rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d /tmp/pi_$sk -- python3 $ROOT/bench.py --obs 100000 --steps 1 --warmup 1 --no-cpu > /tmp/pi_$sk.log 2>&1 || tail -3 /tmp/pi_$sk.log
   python3 - <<PY
