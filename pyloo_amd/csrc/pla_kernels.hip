@@ -205,10 +205,11 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, hipStream_t 
   while ((root_ + 1) * (root_ + 1) <= p.tail_count) ++root_;
   const int mestM = 30 + root_;
   FastParams f{gsz, kq, p.slow_list, p.counters, dbg, p.l1_table, std::log((double)p.n_draws), p.l1_table + p.tail_count, mestM};
-  // one wave per workgroup; 8 x 2048 workgroups keep all 256 CUs (8 waves each) busy with a short tail
-  int64_t grid = p.n_obs;
-  if (grid > 2048 * 8) grid = 2048 * 8;
-  hipLaunchKernelGGL((wave_loo_kernel<T, VEC>), dim3((unsigned)grid), dim3(kWave), 0, stream, p, f);
+  // 4 independent waves per workgroup (they share the read-only tables); 8 x 2048 waves keep all
+  // 256 CUs (8 waves each) busy with a short tail
+  int64_t grid = (p.n_obs + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (grid > 2048 * 8 / kWavesPerBlock) grid = 2048 * 8 / kWavesPerBlock;
+  hipLaunchKernelGGL((wave_loo_kernel<T, VEC>), dim3((unsigned)grid), dim3(kWave * kWavesPerBlock), 0, stream, p, f);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   // general kernel over whatever the fast path declined (usually nothing)

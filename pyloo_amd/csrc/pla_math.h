@@ -94,8 +94,8 @@ __device__ __forceinline__ double div_fast(double a, double d) {
   return fma(fma(-q, d, a), r, q);
 }
 
-// natural log.  Main path for positive normal x (fdlibm e_log.c kernel, <1 ulp); zero, negative,
-// NaN, inf and subnormal inputs are patched up afterwards so the IEEE results match log().
+// natural log (fdlibm e_log.c kernel, <1 ulp); zero, negative, NaN, inf and subnormal inputs are
+// patched up afterwards so the IEEE results match log().  Only used off the hot path now.
 __device__ __forceinline__ double log_fast(double x) {
   const bool sub = (x < 2.2250738585072014e-308) && (x > 0.0);
   const double xs = sub ? x * 18014398509481984.0 : x;  // 2^54
@@ -117,6 +117,44 @@ __device__ __forceinline__ double log_fast(double x) {
   if (x < 0.0) res = qnan();
   if (x != x) res = x;
   if (x == pinf()) res = x;
+  return res;
+}
+
+// ---- table-driven natural log --------------------------------------------------------------------
+// x = 2^e * m with m in [sqrt(1/2), sqrt(2)) (so that x ~ 1 gives e = 0 and no cancellation between
+// e ln2 and log m).  The low exponent bit and the top 7 mantissa bits of m pick a cell with centre c_j,
+// |m/c_j - 1| < 2^-7; log m = log c_j + log1p(m/c_j - 1), the latter a degree-7 polynomial.  The two
+// cells that touch m = 1 use c = 1 exactly, so log x keeps full RELATIVE accuracy as x -> 1.
+// Entry j (16 bytes): {1/c_j, log c_j}; j < 128: binade [1/2, 1), j >= 128: binade [1, 2) (all cells
+// are valid, so a mantissa that lands just outside [sqrt(1/2), sqrt(2)) by rounding is harmless).
+constexpr int kLogTabN = 256;
+__device__ __forceinline__ void log_table_entry(double* lt, int j) {
+  double c = (j < 128) ? 0.5 * (1.0 + ((double)j + 0.5) * (1.0 / 128.0)) : 1.0 + ((double)(j - 128) + 0.5) * (1.0 / 128.0);
+  if (j == 127 || j == 128) c = 1.0;  // the cells adjacent to m = 1
+  lt[2 * j] = 1.0 / c;
+  lt[2 * j + 1] = log(c);
+}
+// positive normal x: ~1 ulp of max(|log x|, 2^-52 |log x|...) -- absolute error < 2.5e-16 + 1.2e-16 |log x|.
+// Everything else (0, negatives, NaN, inf, subnormals) takes the wave-uniform slow branch.
+__device__ __forceinline__ double log_tab(double x, const double* lt) {
+  // e = exponent of x * sqrt(2) - 1  ->  m = x * 2^-e in [sqrt(1/2), sqrt(2))
+  const int e = __builtin_amdgcn_frexp_exp(x * 1.41421356237309504880) - 1;
+  const double m = __builtin_amdgcn_ldexp(x, -e);
+  const int j = (__double2hiint(m) >> 13) & (kLogTabN - 1);  // exponent lsb | mantissa[51:45]
+  const double2 cj = *reinterpret_cast<const double2*>(lt + 2 * j);
+  const double r = fma(m, cj.x, -1.0);  // |r| < 2^-7, exact cancellation of the leading bits
+  double q = fma(r, 1.42857142857142857143e-01, -1.66666666666666666667e-01);
+  q = fma(q, r, 0.2);
+  q = fma(q, r, -0.25);
+  q = fma(q, r, 3.33333333333333333333e-01);
+  q = fma(q, r, -0.5);
+  const double l1p = fma(r * r, q, r);
+  double res = fma((double)e, 6.93147180559945309417e-01, cj.y) + l1p;
+  const bool ok = __builtin_amdgcn_class(x, 0x100);  // positive normal
+  if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {
+    const double alt = log_fast(x);
+    if (!ok) res = alt;
+  }
   return res;
 }
 

@@ -86,15 +86,36 @@ __device__ __forceinline__ float vmax_nc(float a, float b) {
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// cross-lane move whose result is only meaningful in the lanes the control selects (rows masked out
+// by ROWMASK keep whatever the destination register held)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_mov_u(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, ROWMASK, 0xF, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, ROWMASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double vmin_nc(double a, double b) {
+  double d;
+  asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+template <RedOp OP>
+__device__ __forceinline__ double red2(double a, double b) {
+  if constexpr (OP == R_SUM) return a + b;
+  else if constexpr (OP == R_MAX) return vmax_nc<false>(a, b);
+  else return vmin_nc(a, b);
+}
+// Wave-wide reduction, result wave-uniform.  Three instructions per step: the last two steps
+// (row_bcast) only produce valid data in the rows on the path to lane 63, which is the lane read.
+// max / min do not canonicalise: NaNs are ignored (callers test finiteness separately).
 template <RedOp OP>
 __device__ __forceinline__ double wave_all(double v) {
-  const double id = (OP == R_SUM) ? 0.0 : ((OP == R_MAX) ? -pinf() : pinf());
-  v = red_apply<OP>(v, dpp_mov<0xB1, 0xF>(v, id));   // quad_perm [1,0,3,2]
-  v = red_apply<OP>(v, dpp_mov<0x4E, 0xF>(v, id));   // quad_perm [2,3,0,1]
-  v = red_apply<OP>(v, dpp_mov<0x141, 0xF>(v, id));  // row_half_mirror
-  v = red_apply<OP>(v, dpp_mov<0x140, 0xF>(v, id));  // row_mirror: every lane has its row's result
-  v = red_apply<OP>(v, dpp_mov<0x142, 0xA>(v, id));  // row_bcast:15 into rows 1 and 3
-  v = red_apply<OP>(v, dpp_mov<0x143, 0xC>(v, id));  // row_bcast:31 into rows 2 and 3
+  v = red2<OP>(v, dpp_mov_u<0xB1, 0xF>(v));   // quad_perm [1,0,3,2]
+  v = red2<OP>(v, dpp_mov_u<0x4E, 0xF>(v));   // quad_perm [2,3,0,1]
+  v = red2<OP>(v, dpp_mov_u<0x141, 0xF>(v));  // row_half_mirror
+  v = red2<OP>(v, dpp_mov_u<0x140, 0xF>(v));  // row_mirror: every lane has its row's result
+  v = red2<OP>(v, dpp_mov_u<0x142, 0xA>(v));  // row_bcast:15 into rows 1 and 3
+  v = red2<OP>(v, dpp_mov_u<0x143, 0xC>(v));  // row_bcast:31 into rows 2 and 3: lane 63 has it all
   return lane_value(v, 63);
 }
 
@@ -104,10 +125,16 @@ struct WaveSmem {
   double cand[kCandCap + 2 * kWave];  // candidate x values (+ 64 overflow slots + one dump slot per lane); reused for the
                                     // candidates sorted descending once they are binned
   double sa[kWaveCap];              // candidates at/above the boundary bin, grouped by bin; later y ascending
-  double tab[2 * kTabN];            // {2^(j/256), 2^(-j/256)} interleaved: one 16-byte read serves both exponentials
+};
+// read-only tables shared by the waves of a workgroup
+struct WaveTables {
+  double tab[2 * kTabN];            // biased {2^(j/256), 2^(-j/256)} pairs (pla_math.h): one 16-byte read serves both exponentials
+  double lt[2 * kLogTabN];          // {1/c_j, log c_j} for log_tab (pla_math.h)
   double l1[kWaveMaxTail + 6];      // log1p(-(j+0.5)/M), j < M  (host libm, psis.py:153,219-221)
   double bg[kWave];                 // 1 - sqrt(m_est/(j+0.5)) for m_est(M)  (psis.py:186)
 };
+constexpr int kWavesPerBlock = 4;   // independent waves per workgroup (they only share the tables)
+__device__ __forceinline__ int wave_lane() { return (int)threadIdx.x & (kWave - 1); }
 
 // phase ablation for profiling (tools/ablate.sh); compiled out of the production kernel
 #ifndef PLA_WAVE_ABLATE
@@ -127,6 +154,13 @@ __device__ __forceinline__ int mad_i24(int a, int b, int c) {
   asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
   return d;
 }
+// raw LDS byte address of an object in shared memory / store through one
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void lds_store(unsigned addr, double v) {
+  *(__attribute__((address_space(3))) double*)(uintptr_t)addr = v;
+}
 // (k & 255) << sh in one VALU op (SDWA byte select); sh lives in a VGPR
 __device__ __forceinline__ unsigned byte0_shl(int k, int sh) {
   unsigned d;
@@ -143,7 +177,7 @@ template <typename T, int VEC>
 __device__ __forceinline__ void issue_row_loads(T (&v)[kWaveSlots], const T* rp, int S) {
   constexpr int NQ = kWaveSlots / VEC;
   typedef int v4i __attribute__((ext_vector_type(4)));
-  const int lane = threadIdx.x;
+  const int lane = wave_lane();
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(rp), 0, S * (int)sizeof(T), 0x00020000);
 #pragma unroll
@@ -163,7 +197,7 @@ __device__ __forceinline__ void issue_row_loads(T (&v)[kWaveSlots], const T* rp,
 template <typename T, int VEC>
 __device__ __forceinline__ void issue_row_vector(T (&v)[kWaveSlots], const __amdgpu_buffer_rsrc_t rs, int q) {
   typedef int v4i __attribute__((ext_vector_type(4)));
-  const v4i t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)threadIdx.x * 16, q * (kWave * 16), 2 /* nt */);
+  const v4i t = __builtin_amdgcn_raw_buffer_load_b128(rs, wave_lane() * 16, q * (kWave * 16), 2 /* nt */);
   if constexpr (VEC == 2) {
     v[2 * q] = (T)__hiloint2double(t[1], t[0]);
     v[2 * q + 1] = (T)__hiloint2double(t[3], t[2]);
@@ -182,7 +216,7 @@ __device__ __forceinline__ void pad_tail(T (&v)[kWaveSlots], int qfull, int qrem
   if constexpr (Q >= 1) {
     if (Q >= qfull) {
       asm volatile("");  // keep the branch
-      const bool ok = (Q == qfull) && ((int)threadIdx.x < qrem);
+      const bool ok = (Q == qfull) && (wave_lane() < qrem);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) v[Q * VEC + e] = ok ? v[Q * VEC + e] : (CONST ? padv : v[e]);
       pad_tail<T, VEC, Q - 1, CONST>(v, qfull, qrem, padv);
@@ -191,11 +225,11 @@ __device__ __forceinline__ void pad_tail(T (&v)[kWaveSlots], int qfull, int qrem
 }
 
 template <typename T, int VEC>
-__device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParams& F, WaveSmem& sm, const int64_t r,
+__device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParams& F, WaveSmem& sm, const WaveTables& tb, const int64_t r,
                                             T (&v)[kWaveSlots], const T* rp_next) {
   constexpr int EPT = kWaveSlots;
   constexpr int NQ = EPT / VEC;
-  const int lane = threadIdx.x;
+  const int lane = wave_lane();
   // parameters arrive by reference (memory): read each once into scalar registers
   const int S = __builtin_amdgcn_readfirstlane(P.n_draws);
   const int M = __builtin_amdgcn_readfirstlane(P.tail_count);
@@ -206,8 +240,8 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
 #else
   constexpr int dbgs = 0;
 #endif
-  const double* l1tab = sm.l1;
-  const double* bgrid = sm.bg;
+  const double* l1tab = tb.l1;
+  const double* bgrid = tb.bg;
   const int mestM = __builtin_amdgcn_readfirstlane(F.mest_M);
   const double logS = uniform_d(F.log_S);
   const double INF = pinf();
@@ -270,7 +304,9 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   if (kpad >= k1) slow = true;               // pads would be counted as candidates
   double khat = INF, loo = 0.0, lppd = 0.0;
   bool streamed = false;  // next row's loads already issued (inside the sweep)
-  if (!slow) {
+  if (dbgs & 16) {
+    loo = t1 + R;  // ablation: statistics and threshold only
+  } else if (!slow) {
     // bins over the candidates: (k - k1) >> sh  in [0, 511] for k in [k1, 0]
     const int span = -k1;
     const int sh = (span >> 9) ? (32 - __builtin_clz((unsigned)(span >> 9))) : 0;
@@ -297,15 +333,19 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     asm volatile("" : "+s"(c256), "+s"(nl256), "+s"(c6), "+s"(c4096), "+s"(cm4096));
     int four = 4;
     asm volatile("" : "+v"(four));
-    unsigned ncand8 = 0;                                 // 8 * candidates so far (wave-uniform)
     // the next row (a zero-length range when there is none: the loads then return zeros and touch nothing)
     const __amdgpu_buffer_rsrc_t rs_next = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>(rp_next ? rp_next : (const T*)P.in), 0, rp_next ? S * (int)sizeof(T) : 0, 0x00020000);
     streamed = true;
-    const char* tabc = reinterpret_cast<const char*>(sm.tab);
-    char* candc = reinterpret_cast<char*>(sm.cand);
-    const unsigned dump8 = (unsigned)(kCandCap + kWave + lane) * 8u;  // this lane's dump slot
-    unsigned base8 = 0;                                   // 8 * min(ncand, kCandCap): byte offset of the next append
+    const char* tabc = reinterpret_cast<const char*>(tb.tab);
+    // The candidate list is addressed with raw LDS byte addresses so that this wave's scratch base
+    // rides in the scalar append offset / the precomputed dump address instead of costing a vector
+    // add per draw.
+    const unsigned cand0 = lds_addr(sm.cand);
+    const unsigned dump8 = cand0 + (unsigned)(kCandCap + kWave + lane) * 8u;  // this lane's dump slot
+    const unsigned lim8 = cand0 + 8u * kCandCap;
+    unsigned next8 = cand0;                               // address of the next append (unclamped)
+    unsigned base8 = cand0;                               // min(next8, lim8)
     // Software pipeline, kPF draws deep: stage A of draw i+kPF (shift, range reduction, table read,
     // candidate append) is issued before stage B of draw i (polynomial, accumulate), so the LDS
     // latency of the table read is covered by the arithmetic of the draws in between.
@@ -347,9 +387,12 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
         unsigned pos8 = (rank << 3) + base8;
         asm("" : "+v"(pos8));  // computed by every lane: a select below, not a divergent region
-        *reinterpret_cast<double*>(candc + (cand ? pos8 : dump8)) = x;
-        ncand8 += (unsigned)__popcll(cm) << 3;
-        base8 = ncand8 < (unsigned)(8 * kCandCap) ? ncand8 : (unsigned)(8 * kCandCap);
+        lds_store(cand ? pos8 : dump8, x);
+        {  // next8 += 8 * popcount(cm) in two scalar ops (the compiler would re-associate it into four)
+          const unsigned pc = (unsigned)__popcll(cm);
+          asm("s_lshl3_add_u32 %0, %1, %0" : "+s"(next8) : "s"(pc) : "scc");
+        }
+        base8 = next8 < lim8 ? next8 : lim8;
         // This was the last read of slot i.  Once a whole 16-byte vector has been consumed, the next
         // row's vector is streamed into the same registers: the loads of row r+1 trickle out during
         // the sweep of row r and have the whole selection / fit / smoothing phase to arrive, without a
@@ -357,7 +400,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         if ((i % VEC) == VEC - 1) issue_row_vector<T, VEC>(v, rs_next, i / VEC);
       }
     }
-    const unsigned ncand = ncand8 >> 3;
+    const unsigned ncand = (next8 - cand0) >> 3;
     PLA_PHASE(3);
     {  // remove the pads' contribution (same code path, so it cancels to rounding)
       const double x = -R;
@@ -459,13 +502,13 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         const double xcut = sb[M];
         int n = M;
         while (n > 0 && sb[n - 1] == xcut) --n;  // ties at the cutoff leave the tail
-        const double e_cut = exp_tab(xcut, sm.tab);
+        const double e_cut = exp_tab(xcut, tb.tab);
         double acc_t = 0.0, acc_r = 0.0;  // (sum w' - sum e) and sum w'/e over the tail
         bool smoothed = false;
         if (n > 4 && !(dbgs & 8)) {
           wave_sync();
           // y ascending (psis.py:146-147), stored with the pair sums / products the fit loop eats
-          for (int j = lane; j < n; j += kWave) sm.sa[j] = exp_tab(sb[n - 1 - j], sm.tab) - e_cut;
+          for (int j = lane; j < n; j += kWave) sm.sa[j] = exp_tab(sb[n - 1 - j], tb.tab) - e_cut;
           wave_sync();
           const double* y = sm.sa;
           const double nn = (double)n;
@@ -533,12 +576,12 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           acc.m *= acc2.m;
           acc.e += acc2.e;
           const double rn = recip_fast(nn);
-          const double kj = ((log_fast(acc.m) + (double)acc.e * kLn2) + corr) * rn;   // psis.py:190
-          const double ls = nn * (log_fast(-div_fast(b, kj)) - kj - 1.0);             // psis.py:191
+          const double kj = ((log_tab(acc.m, tb.lt) + (double)acc.e * kLn2) + corr) * rn;   // psis.py:190
+          const double ls = nn * (log_tab(act ? -div_fast(b, kj) : 1.0, tb.lt) - kj - 1.0);             // psis.py:191
           const double lmax = wave_all<R_MAX>(act ? ls : -INF);
           // NaN anywhere, or max = +-inf: every weight is NaN in the reference -> nothing is kept
           const bool anynan = (__ballot(act && (ls != ls)) != 0ull) || !(fabs(lmax) < INF);
-          double w = act ? exp_neg(ls - lmax, sm.tab) : 0.0;                          // psis.py:192
+          double w = act ? exp_neg(ls - lmax, tb.tab) : 0.0;                          // psis.py:192
           const double se = wave_all<R_SUM>(w);
           w = anynan ? qnan() : w * recip_fast(se);
           const bool keep = act && (w >= 10.0 * kEps);                                // psis.py:194-197
@@ -549,7 +592,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           PLA_PHASE(12);
           double pr = 1.0;
           for (int ii = lane; ii < n; ii += kWave) pr *= fma(-b_post, y[ii], 1.0);
-          const double k_post = wave_all<R_SUM>(log_fast(pr)) * rn;
+          const double k_post = wave_all<R_SUM>(log_tab(pr, tb.lt)) * rn;
           const double sigma = -k_post / b_post;                                      // psis.py:205
           khat = (nn * k_post + 5.0) / (nn + 10.0);                                   // psis.py:206
           PLA_PHASE(13);
@@ -564,7 +607,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
               if (sigma <= 0.0) {
                 q = qnan();                                                           // psis.py:214-215
               } else {
-                q = ktiny ? -l1 : expm1_tab(-khat * l1, sm.tab) * rk;                 // psis.py:218-221
+                q = ktiny ? -l1 : expm1_tab(-khat * l1, tb.tab) * rk;                 // psis.py:218-221
                 q *= sigma;
               }
               double wj = q + e_cut;   // exp(log(q + e_cut)), psis.py:155
@@ -582,8 +625,10 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         // loo_i = -m - L + log(tail_ratio),  L = log(total) (psis.py:158; loo.py:289,319-324): one log
         double tail_ratio = (double)S;
         if (smoothed) tail_ratio = (double)(S - n) + wave_all<R_SUM>(acc_r);
-        loo = log_fast(div_fast(tail_ratio, total)) - m;
-        lppd = (log_fast(s2) - R) + ((-mn) - logS);                           // loo.py:329-337
+        // the two logs of the row in one call: lane 1 takes s2, every other lane the weight ratio
+        const double lg = log_tab(lane == 1 ? s2 : div_fast(tail_ratio, total), tb.lt);
+        loo = lane_value(lg, 0) - m;
+        lppd = (lane_value(lg, 1) - R) + ((-mn) - logS);                      // loo.py:329-337
         if ((!(total > 1e-280) || !isfinite(loo) || !isfinite(lppd)) && !(dbgs & 63)) slow = true;
       }
     }
@@ -608,23 +653,24 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
 // loop-invariant constant, mask and offset of the later phases above the loop, where they sit on
 // top of the 128 row registers and spill.
 template <typename T, int VEC>
-__global__ __launch_bounds__(kWave, 2) void wave_loo_kernel(RowsParams P, FastParams F) {
-  __shared__ __attribute__((aligned(16))) WaveSmem sm;
-  const int lane = threadIdx.x;
-#pragma unroll
-  for (int i = 0; i < kTabN / kWave; ++i) {
-    const int j = lane + kWave * i;
-    exp_table_entry(sm.tab, j);
-  }
-  for (int j = lane; j < P.tail_count; j += kWave) sm.l1[j] = F.l1_table[j];
-  sm.bg[lane] = F.b_grid[lane];
-  wave_sync();
+__global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void wave_loo_kernel(RowsParams P, FastParams F) {
+  __shared__ __attribute__((aligned(16))) WaveSmem scratch[kWavesPerBlock];
+  __shared__ __attribute__((aligned(16))) WaveTables tb;
+  const int tid = threadIdx.x;
+  for (int j = tid; j < kTabN; j += kWave * kWavesPerBlock) exp_table_entry(tb.tab, j);
+  for (int j = tid; j < kLogTabN; j += kWave * kWavesPerBlock) log_table_entry(tb.lt, j);
+  for (int j = tid; j < P.tail_count; j += kWave * kWavesPerBlock) tb.l1[j] = F.l1_table[j];
+  if (tid < kWave) tb.bg[tid] = F.b_grid[tid];
+  __syncthreads();  // the only workgroup barrier: from here on the waves are independent
+  const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);  // wave-uniform, and the compiler knows it
+  WaveSmem& sm = scratch[wv];
   T v[kWaveSlots];
   const T* base = reinterpret_cast<const T*>(P.in);
-  if ((int64_t)blockIdx.x < P.n_obs) issue_row_loads<T, VEC>(v, base + (int64_t)blockIdx.x * P.stride_obs, P.n_draws);
-  for (int64_t r = blockIdx.x; r < P.n_obs; r += gridDim.x) {
-    const int64_t rn = r + gridDim.x;
-    wave_loo_row<T, VEC>(P, F, sm, r, v, rn < P.n_obs ? base + rn * P.stride_obs : nullptr);
+  const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + wv, nw = (int64_t)gridDim.x * kWavesPerBlock;
+  if (w0 < P.n_obs) issue_row_loads<T, VEC>(v, base + w0 * P.stride_obs, P.n_draws);
+  for (int64_t r = w0; r < P.n_obs; r += nw) {
+    const int64_t rn = r + nw;
+    wave_loo_row<T, VEC>(P, F, sm, tb, r, v, rn < P.n_obs ? base + rn * P.stride_obs : nullptr);
   }
 }
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Phase ablation of the wave kernel (profiling aid).  Uses a separate build with PLA_WAVE_ABLATE=1;
 # PLA_DEBUG_SKIP bits: 1 no exponentials, 2 no histogram atomics, 4 stop after the sweep,
-# 8 no GPD fit / smoothing.  Results of ablated runs are meaningless; only the times matter.
+# 8 no GPD fit / smoothing, 16 statistics + threshold only.  Results of ablated runs are meaningless; only the times matter.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 LIB=$ROOT/pyloo_amd/lib/libpyloo_amd_ablate.so
