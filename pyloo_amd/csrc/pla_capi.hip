@@ -315,6 +315,15 @@ int pla_psis_loo(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int6
       TimedLaunch t(eng, s);
       PLA_HIP(pla::launch_rows(p, dtype, false, s));
     }
+#if defined(PLA_WAVE_ABLATE) && PLA_WAVE_ABLATE
+    if (getenv("PLA_PRINT_CLOCK")) {  // profiling build only: core clock seen by one wave of the fast kernel
+      unsigned long long h[4];
+      PLA_HIP(hipStreamSynchronize(s));
+      PLA_HIP(hipMemcpy(h, eng->counters, sizeof(h), hipMemcpyDeviceToHost));
+      if (h[3]) fprintf(stderr, "[pla] core clock %.1f MHz (%llu core ticks / %llu ticks of 100 MHz)\n",
+                        100.0 * (double)h[2] / (double)h[3], h[2], h[3]);
+    }
+#endif
     if (agg) {
       pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, agg, eng->counters + 1};
       PLA_HIP(pla::launch_reduce(rp, eng->d_red, s));

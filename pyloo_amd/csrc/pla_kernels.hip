@@ -58,8 +58,8 @@ __global__ __launch_bounds__(BLOCK) void slow_rows_kernel(RowsParams P) {
 
 // loo.py:326-342 + 292-293 in two deterministic launches.  Stage 1: every workgroup reduces its own
 // contiguous chunk to (n, sum, M2 about the chunk mean, ...); np.var is a two-pass formula as well
-// and the chunk is L2-resident for the second pass.  Stage 2: one workgroup merges the chunk moments
-// in chunk order with the pairwise update of Chan, Golub & LeVeque (no cancellation).
+// and the chunk is L2-resident for the second pass.  Stage 2: one wave merges the chunk moments with
+// the pairwise update of Chan, Golub & LeVeque (no cancellation) in a fixed order.
 constexpr int kRedBlock = 256;
 constexpr int kRedChunks = 1024;
 constexpr int kRedSlots = 8;  // n, sum loo, M2, sum lppd, #high, #non-finite, min diag, unused
@@ -101,23 +101,41 @@ __global__ __launch_bounds__(kRedBlock) void reduce_stage1(ReduceParams P, doubl
   }
 }
 
+struct Moments {  // count, mean and M2 of loo_i over a set of observations + the plain sums
+  double n, mean, m2, s_loo, s_lppd, n_high, n_bad, dmin;
+};
+__device__ __forceinline__ void merge_moments(Moments& a, const Moments& b) {  // Chan, Golub & LeVeque
+  if (b.n == 0.0) return;
+  if (a.n == 0.0) { a = b; return; }
+  const double delta = b.mean - a.mean, tot = a.n + b.n;
+  a.m2 += b.m2 + delta * delta * a.n * b.n / tot;
+  a.mean += delta * b.n / tot;
+  a.n = tot;
+  a.s_loo += b.s_loo; a.s_lppd += b.s_lppd; a.n_high += b.n_high; a.n_bad += b.n_bad;
+  a.dmin = fmin(a.dmin, b.dmin);
+}
+
+// One wave: lane l merges chunks l*per .. (l+1)*per-1 in order, then the 64 partial results are merged
+// by a fixed shuffle tree.  The grouping depends only on the chunk count, so the result is
+// reproducible run to run.
 __global__ __launch_bounds__(kWave) void reduce_stage2(ReduceParams P, const double* part, int nchunks) {
-  if (threadIdx.x != 0) return;  // a few hundred serial flops: determinism over parallelism
-  double n = 0.0, mean = 0.0, m2 = 0.0, s_loo = 0.0, s_lppd = 0.0, n_high = 0.0, n_bad = 0.0, dmin = pinf();
-  for (int c = 0; c < nchunks; ++c) {
+  const int lane = threadIdx.x;
+  const int per = (nchunks + kWave - 1) / kWave;
+  Moments a{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, pinf()};
+  for (int c = lane * per; c < (lane + 1) * per && c < nchunks; ++c) {
     const double* o = part + (size_t)c * kRedSlots;
-    const double nb = o[0];
-    if (nb == 0.0) continue;
-    const double mb = o[1] / nb;
-    if (n == 0.0) { n = nb; mean = mb; m2 = o[2]; }
-    else {
-      const double delta = mb - mean, tot = n + nb;
-      m2 += o[2] + delta * delta * n * nb / tot;
-      mean += delta * nb / tot;
-      n = tot;
-    }
-    s_loo += o[1]; s_lppd += o[3]; n_high += o[4]; n_bad += o[5]; dmin = fmin(dmin, o[6]);
+    Moments b{o[0], o[0] > 0.0 ? o[1] / o[0] : 0.0, o[2], o[1], o[3], o[4], o[5], o[6]};
+    merge_moments(a, b);
   }
+  for (int off = 1; off < kWave; off <<= 1) {
+    Moments b;
+    b.n = __shfl_down(a.n, off); b.mean = __shfl_down(a.mean, off); b.m2 = __shfl_down(a.m2, off);
+    b.s_loo = __shfl_down(a.s_loo, off); b.s_lppd = __shfl_down(a.s_lppd, off);
+    b.n_high = __shfl_down(a.n_high, off); b.n_bad = __shfl_down(a.n_bad, off); b.dmin = __shfl_down(a.dmin, off);
+    if ((lane & (2 * off - 1)) == 0 && lane + off < kWave) merge_moments(a, b);
+  }
+  if (lane != 0) return;
+  const double s_loo = a.s_loo, m2 = a.m2, s_lppd = a.s_lppd, n_high = a.n_high, n_bad = a.n_bad, dmin = a.dmin;
   P.agg[PLA_AGG_N] = (double)P.n_obs;
   P.agg[PLA_AGG_SUM_LOO] = s_loo;
   P.agg[PLA_AGG_M2_LOO] = m2;

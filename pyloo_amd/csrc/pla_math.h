@@ -55,6 +55,16 @@ __device__ __forceinline__ double exp_tab(double x, const double* tab) {
   const double O = fma(1.66666666666666666667e-01, r2, 1.0);
   return __hiloint2double(__double2hiint(tj) + (q.k << 12), __double2loint(tj)) * fma(q.r, O, E);
 }
+// e^x and e^-x from one range reduction, x in [-700, 700]
+__device__ __forceinline__ void exp_pair(double x, const double* tab, double& ep, double& en) {
+  const Red256 q = reduce256(x);
+  const double2 tj = *reinterpret_cast<const double2*>(tab + 2 * (q.k & 255));
+  const double r2 = q.r * q.r;
+  const double E = fma(fma(4.16666666666666666667e-02, r2, 0.5), r2, 1.0);
+  const double O = fma(1.66666666666666666667e-01, r2, 1.0);
+  ep = __hiloint2double(__double2hiint(tj.x) + (q.k << 12), __double2loint(tj.x)) * fma(q.r, O, E);
+  en = __hiloint2double(__double2hiint(tj.y) - (q.k << 12), __double2loint(tj.y)) * fma(-q.r, O, E);
+}
 // e^x for any x <= 0 (and NaN -> caller's problem): clamps where e^x underflows anyway
 __device__ __forceinline__ double exp_neg(double x, const double* tab) { return exp_tab(fmax(x, -700.0), tab); }
 

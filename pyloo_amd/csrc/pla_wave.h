@@ -35,9 +35,21 @@
 
 namespace pla {
 
-constexpr int kWaveSlots = 64;   // register slots per lane -> S <= 4096
+#ifndef PLA_WAVE_SLOTS
+#define PLA_WAVE_SLOTS 64
+#endif
+#ifndef PLA_CAND_CAP
+#define PLA_CAND_CAP 896
+#endif
+#ifndef PLA_WAVES_PER_BLOCK
+#define PLA_WAVES_PER_BLOCK 4
+#endif
+#ifndef PLA_MIN_WAVES_PER_SIMD
+#define PLA_MIN_WAVES_PER_SIMD 2
+#endif
+constexpr int kWaveSlots = PLA_WAVE_SLOTS;   // register slots per lane -> S <= 4096
 constexpr int kWaveBins = 512;   // histogram bins over the candidate list
-constexpr int kCandCap = 896;    // candidates (draws above the speculative threshold) kept in LDS
+constexpr int kCandCap = PLA_CAND_CAP;    // candidates (draws above the speculative threshold) kept in LDS
 constexpr int kWaveCap = 320;    // candidates kept in LDS; needs M + boundary-bin extras
 constexpr int kWaveMaxTail = 250;
 constexpr double kWaveMaxRange = 690.0;  // nats: e^x, e^-x and their sums over 4096 draws stay finite and normal
@@ -133,7 +145,7 @@ struct WaveTables {
   double l1[kWaveMaxTail + 6];      // log1p(-(j+0.5)/M), j < M  (host libm, psis.py:153,219-221)
   double bg[kWave];                 // 1 - sqrt(m_est/(j+0.5)) for m_est(M)  (psis.py:186)
 };
-constexpr int kWavesPerBlock = 4;   // independent waves per workgroup (they only share the tables)
+constexpr int kWavesPerBlock = PLA_WAVES_PER_BLOCK;   // independent waves per workgroup (they only share the tables)
 __device__ __forceinline__ int wave_lane() { return (int)threadIdx.x & (kWave - 1); }
 
 // phase ablation for profiling (tools/ablate.sh); compiled out of the production kernel
@@ -266,7 +278,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     for (int i = 0; i < EPT; ++i) {
       cur = vmax_nc<true>(v[i], cur);
       vmx = vmax_nc<false>(v[i], vmx);
-      if (i == 3 || i == 7 || i == 15 || i == 31) {  // gsz is one of 4, 8, 16, 32 (wave_threshold_params)
+      if ((i == 3 || i == 7 || i == 15 || i == 31) && i < EPT) {  // gsz is one of 4, 8, 16, 32 (wave_threshold_params)
         if (gsz == i + 1) {
           asm volatile("");  // a real wave-uniform branch, not a select per slot
           snap = cur;
@@ -288,7 +300,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   {
     double lo = wave_all<R_MIN>(gs), hi = m;
 #pragma unroll 1
-    for (int it = 0; it < 12; ++it) {
+    for (int it = 0; it < 9; ++it) {  // 2^-9 of the spread of the group maxima: a handful of candidates
       const double mid = 0.5 * (lo + hi);
       const int below = __popcll(__ballot(gs < mid));
       if (below >= kq) hi = mid; else lo = mid;
@@ -489,10 +501,15 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           const int b = (key256(x) - k1) >> sh;
           const int lo = (int)sm.start[b];
           const int hi = (b > 0) ? (int)sm.start[b - 1] : C1;
-          int cnt = 0;
+          int cnt = 0, same = 0;
           for (int c2 = lo; c2 < hi; ++c2) {
             const double x2 = sm.sa[c2];
-            cnt += (x2 > x || (x2 == x && c2 > c)) ? 1 : 0;
+            cnt += (x2 > x) ? 1 : 0;
+            same += (x2 == x) ? 1 : 0;  // counts the element itself
+          }
+          if (__ballot(same > 1) != 0ull) {  // duplicates (repeated draws): order them by position
+            if (same > 1)
+              for (int c2 = lo; c2 < c; ++c2) cnt += (sm.sa[c2] == x) ? 1 : 0;
           }
           sb[lo + cnt] = x;
         }
@@ -508,7 +525,14 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         if (n > 4 && !(dbgs & 8)) {
           wave_sync();
           // y ascending (psis.py:146-147), stored with the pair sums / products the fit loop eats
-          for (int j = lane; j < n; j += kWave) sm.sa[j] = exp_tab(sb[n - 1 - j], tb.tab) - e_cut;
+          // (the reciprocals e^-x of the same range reduction are kept for the weight ratios below)
+          double* inv_e = sb + kWaveCap + kWave;  // beyond the sorted candidates and the pair data
+          for (int j = lane; j < n; j += kWave) {
+            double ep, en;
+            exp_pair(sb[n - 1 - j], tb.tab, ep, en);
+            sm.sa[j] = ep - e_cut;
+            inv_e[j] = en;
+          }
           wave_sync();
           const double* y = sm.sa;
           const double nn = (double)n;
@@ -597,6 +621,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           khat = (nn * k_post + 5.0) / (nn + 10.0);                                   // psis.py:206
           PLA_PHASE(13);
           if (isfinite(khat)) {
+            const double* inv_e = sb + kWaveCap + kWave;
             smoothed = true;
             const double rk = 1.0 / khat;
             const bool ktiny = fabs(khat) < kEps;
@@ -614,7 +639,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
               if (wj > 1.0) wj = 1.0;  // psis.py:157
               const double ej = y[j] + e_cut;
               acc_t += wj - ej;
-              acc_r += div_fast(wj, ej);
+              acc_r = fma(wj, inv_e[j], acc_r);
             }
           }
         }
@@ -653,7 +678,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
 // loop-invariant constant, mask and offset of the later phases above the loop, where they sit on
 // top of the 128 row registers and spill.
 template <typename T, int VEC>
-__global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void wave_loo_kernel(RowsParams P, FastParams F) {
+__global__ __launch_bounds__(kWave * kWavesPerBlock, PLA_MIN_WAVES_PER_SIMD) void wave_loo_kernel(RowsParams P, FastParams F) {
   __shared__ __attribute__((aligned(16))) WaveSmem scratch[kWavesPerBlock];
   __shared__ __attribute__((aligned(16))) WaveTables tb;
   const int tid = threadIdx.x;
@@ -668,10 +693,22 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void wave_loo_kernel(Row
   const T* base = reinterpret_cast<const T*>(P.in);
   const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + wv, nw = (int64_t)gridDim.x * kWavesPerBlock;
   if (w0 < P.n_obs) issue_row_loads<T, VEC>(v, base + w0 * P.stride_obs, P.n_draws);
+#if PLA_WAVE_ABLATE
+  unsigned long long ck0, rt0;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck0), "=s"(rt0));
+#endif
   for (int64_t r = w0; r < P.n_obs; r += nw) {
     const int64_t rn = r + nw;
     wave_loo_row<T, VEC>(P, F, sm, tb, r, v, rn < P.n_obs ? base + rn * P.stride_obs : nullptr);
   }
+#if PLA_WAVE_ABLATE
+  if (blockIdx.x == 0 && tid == 0) {  // core clock against the 100 MHz real-time counter
+    unsigned long long ck1, rt1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck1), "=s"(rt1));
+    F.counters[2] = ck1 - ck0;
+    F.counters[3] = rt1 - rt0;
+  }
+#endif
 }
 
 }  // namespace pla
