@@ -58,10 +58,11 @@ struct pla_engine {
   int64_t l1_M = -1;
   // timing of the main kernel
   bool timing = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  static constexpr int kTimingRing = 64;  // launches timed without a host-side wait in between
+  hipEvent_t ev0[kTimingRing] = {}, ev1[kTimingRing] = {};
   double acc_ms = 0.0;
   int64_t launches = 0;
-  bool pending = false;
+  int pending = 0;  // event pairs recorded and not yet read back
 };
 
 namespace {
@@ -127,24 +128,25 @@ struct TimedLaunch {  // brackets the main kernel with events when timing is on
   hipStream_t s;
   TimedLaunch(pla_engine* e_, hipStream_t s_) : e(e_), s(s_) {
     if (e->timing) {
-      if (e->pending) flush(e);
-      (void)hipEventRecord(e->ev0, s);
+      if (e->pending == pla_engine::kTimingRing) flush(e);  // the only case in which the host waits
+      (void)hipEventRecord(e->ev0[e->pending], s);
     }
   }
   ~TimedLaunch() {
     if (e->timing) {
-      (void)hipEventRecord(e->ev1, s);
-      e->pending = true;
+      (void)hipEventRecord(e->ev1[e->pending], s);
+      e->pending += 1;
     }
   }
   static void flush(pla_engine* e) {
-    if (!e->pending) return;
-    float ms = 0.f;
-    if (hipEventSynchronize(e->ev1) == hipSuccess && hipEventElapsedTime(&ms, e->ev0, e->ev1) == hipSuccess) {
-      e->acc_ms += ms;
-      e->launches += 1;
+    for (int i = 0; i < e->pending; ++i) {
+      float ms = 0.f;
+      if (hipEventSynchronize(e->ev1[i]) == hipSuccess && hipEventElapsedTime(&ms, e->ev0[i], e->ev1[i]) == hipSuccess) {
+        e->acc_ms += ms;
+        e->launches += 1;
+      }
     }
-    e->pending = false;
+    e->pending = 0;
   }
 };
 
@@ -181,8 +183,10 @@ int pla_engine_create(int device, pla_engine** out) {
   hipError_t he = hipMalloc((void**)&e->counters, 4 * sizeof(unsigned long long));
   if (he == hipSuccess) he = hipMalloc((void**)&e->d_red, (size_t)pla::reduce_workspace_doubles() * sizeof(double));
   if (he == hipSuccess) he = hipMemset(e->counters, 0, 4 * sizeof(unsigned long long));
-  if (he == hipSuccess) he = hipEventCreate(&e->ev0);
-  if (he == hipSuccess) he = hipEventCreate(&e->ev1);
+  for (int i = 0; i < pla_engine::kTimingRing && he == hipSuccess; ++i) {
+    he = hipEventCreate(&e->ev0[i]);
+    if (he == hipSuccess) he = hipEventCreate(&e->ev1[i]);
+  }
   if (he != hipSuccess) {
     pla_engine_destroy(e);
     return fail(PLA_ERR_HIP, "engine setup: %s", hipGetErrorString(he));
@@ -201,8 +205,10 @@ int pla_engine_destroy(pla_engine* e) {
   if (e->d_pw) (void)hipFree(e->d_pw);
   if (e->d_slow) (void)hipFree(e->d_slow);
   if (e->d_l1) (void)hipFree(e->d_l1);
-  if (e->ev0) (void)hipEventDestroy(e->ev0);
-  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  for (int i = 0; i < pla_engine::kTimingRing; ++i) {
+    if (e->ev0[i]) (void)hipEventDestroy(e->ev0[i]);
+    if (e->ev1[i]) (void)hipEventDestroy(e->ev1[i]);
+  }
   delete e;
   return PLA_OK;
 }

@@ -311,8 +311,14 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   // and is caught by the finiteness test at the end: both land on the general kernel
   PLA_PHASE(1);
   bool slow = !(R < kWaveMaxRange) || !(t1 < 0.0);
-  const int k1 = key256(t1);                 // histogram origin
-  const int kpad = key256(-R);               // key of the pad value (smallest x of the row)
+  // constants every later phase uses, pinned in registers by hand (MachineLICM is off for this file:
+  // the compiler would otherwise re-materialise them inside every loop)
+  double magic = kMagic, c256 = kC256;
+  asm volatile("" : "+v"(magic));
+  asm volatile("" : "+s"(c256));
+  const auto key_of = [&](double xx) { return __double2loint(fma(xx, c256, magic)); };  // = key256, hoisted
+  const int k1 = key_of(t1);                 // histogram origin
+  const int kpad = key_of(-R);               // key of the pad value (smallest x of the row)
   if (kpad >= k1) slow = true;               // pads would be counted as candidates
   double khat = INF, loo = 0.0, lppd = 0.0;
   bool streamed = false;  // next row's loads already issued (inside the sweep)
@@ -336,13 +342,11 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     // (e^(ll - max ll) = e^-R * e^-x; the row constant e^-R is applied to the sum, in log space)
     PLA_PHASE(2);
     double s1 = 0.0, s2 = 0.0;
-    double magic = kMagic;
-    asm volatile("" : "+v"(magic));  // keep it resident instead of re-materialising per draw
     // the constants of the sweep live in SGPRs for its whole length (with MachineLICM off the compiler
     // would re-materialise each of them with s_mov per use)
-    double c256 = kC256, nl256 = -kLn2_256, c6 = 1.66666666666666666667e-01;
+    double nl256 = -kLn2_256, c6 = 1.66666666666666666667e-01;
     int c4096 = 4096, cm4096 = -4096;
-    asm volatile("" : "+s"(c256), "+s"(nl256), "+s"(c6), "+s"(c4096), "+s"(cm4096));
+    asm volatile("" : "+s"(nl256), "+s"(c6), "+s"(c4096), "+s"(cm4096));
     int four = 4;
     asm volatile("" : "+v"(four));
     // the next row (a zero-length range when there is none: the loads then return zeros and touch nothing)
@@ -438,7 +442,9 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     } else {
       // ---- 3. histogram of the candidate list, suffix scan (8 bins per lane) ---------------------
       PLA_PHASE(4);
-      for (unsigned c = lane; c < ncand; c += kWave) atomicAdd(&sm.hist[(key256(sm.cand[c]) - k1) >> sh], 1u);
+      unsigned one = 1u;
+      asm volatile("" : "+v"(one));
+      for (unsigned c = lane; c < ncand; c += kWave) atomicAdd(&sm.hist[(key_of(sm.cand[c]) - k1) >> sh], one);
       wave_sync();
       PLA_PHASE(5);
       int bstar = 0, C1 = 0;
@@ -485,7 +491,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         const int kstar = k1 + (bstar << sh);
         for (unsigned c = lane; c < ncand; c += kWave) {
           const double x = sm.cand[c];
-          const int k = key256(x);
+          const int k = key_of(x);
           if (k >= kstar) {
             const int b = (k - k1) >> sh;
             const unsigned slot = sm.start[b] + (atomicSub(&sm.hist[b], 1u) - 1u);
@@ -498,7 +504,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         // ---- 5. exact descending rank inside each bin (ties: arbitrary, the sums do not care) --
         for (int c = lane; c < C1; c += kWave) {
           const double x = sm.sa[c];
-          const int b = (key256(x) - k1) >> sh;
+          const int b = (key_of(x) - k1) >> sh;
           const int lo = (int)sm.start[b];
           const int hi = (b > 0) ? (int)sm.start[b - 1] : C1;
           int cnt = 0, same = 0;
@@ -527,17 +533,18 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           // y ascending (psis.py:146-147), stored with the pair sums / products the fit loop eats
           // (the reciprocals e^-x of the same range reduction are kept for the weight ratios below)
           double* inv_e = sb + kWaveCap + kWave;  // beyond the sorted candidates and the pair data
-          for (int j = lane; j < n; j += kWave) {
+          const int n32 = (n + 31) & ~31;  // padded with y = 0 (factor 1) so that the fit runs whole trips only
+          for (int j = lane; j < n32; j += kWave) {
             double ep, en;
-            exp_pair(sb[n - 1 - j], tb.tab, ep, en);
-            sm.sa[j] = ep - e_cut;
+            exp_pair(sb[j < n ? n - 1 - j : 0], tb.tab, ep, en);
+            sm.sa[j] = j < n ? ep - e_cut : 0.0;
             inv_e[j] = en;
           }
           wave_sync();
           const double* y = sm.sa;
           const double nn = (double)n;
           // (1 - b y0)(1 - b y1) = 1 - b (y0 + y1) + b^2 y0 y1: pair sums / products once per row
-          for (int p2 = lane; 2 * p2 + 1 < n; p2 += kWave) {
+          for (int p2 = lane; 2 * p2 < n32; p2 += kWave) {
             const double2 yy = *reinterpret_cast<const double2*>(y + 2 * p2);
             *reinterpret_cast<double2*>(&sb[2 * p2]) = make_double2(yy.x + yy.y, yy.x * yy.y);
           }
@@ -567,7 +574,9 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           double corr = 0.0;
           int i = 0;
           if (wide && !tiny) {
-            for (; i + 32 <= n; i += 32) {
+            // factors within 2^+-15: four trips (8 pair factors per accumulator each) fit between renorms
+            const bool narrow = (fbig < 0x1p15) && (fsmall > 0x1p-15);
+            for (; i < n32; i += 32) {
 #pragma unroll
               for (int u = 0; u < 32; u += 4) {
                 const double2 pa = *reinterpret_cast<const double2*>(yp + i + u);
@@ -575,18 +584,13 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
                 acc.mul(fma(nb, fma(nb, pa.y, pa.x), 1.0));
                 acc2.mul(fma(nb, fma(nb, pb.y, pb.x), 1.0));
               }
-              acc.renorm();
-              acc2.renorm();
+              if (!narrow || (i & 96) == 96) {
+                acc.renorm();
+                acc2.renorm();
+              }
             }
-            for (; i + 4 <= n; i += 4) {
-              const double2 pa = *reinterpret_cast<const double2*>(yp + i);
-              const double2 pb = *reinterpret_cast<const double2*>(yp + i + 2);
-              acc.mul(fma(nb, fma(nb, pa.y, pa.x), 1.0));
-              acc2.mul(fma(nb, fma(nb, pb.y, pb.x), 1.0));
-            }
-            acc2.renorm();
-            for (; i < n; ++i) acc.mul(fma(nb, y[i], 1.0));
             acc.renorm();
+            acc2.renorm();
           } else {
             for (; i < n; ++i) {
               const double yi = y[i];
