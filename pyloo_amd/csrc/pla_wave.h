@@ -26,6 +26,8 @@
 // list and recomputed by the general kernel (pla_rows.h).
 #pragma once
 
+#include <type_traits>
+
 #include "pla_fast.h"
 #include "pla_math.h"
 
@@ -136,7 +138,7 @@ struct WaveSmem {
   unsigned short start[kWaveBins];  // #candidates in bins above b
   double cand[kCandCap + 2 * kWave];  // candidate x values (+ 64 overflow slots + one dump slot per lane); reused for the
                                     // candidates sorted descending once they are binned
-  double sa[kWaveCap];              // candidates at/above the boundary bin, grouped by bin; later y ascending
+  double sa[kWaveCap + 4];          // candidates at/above the boundary bin, grouped by bin (+ 4 sentinels); later y ascending
 };
 // read-only tables shared by the waves of a workgroup
 struct WaveTables {
@@ -444,7 +446,20 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       PLA_PHASE(4);
       unsigned one = 1u;
       asm volatile("" : "+v"(one));
-      for (unsigned c = lane; c < ncand; c += kWave) atomicAdd(&sm.hist[(key_of(sm.cand[c]) - k1) >> sh], one);
+      // four list entries per lane and trip: the LDS reads go out together instead of one round trip each
+      for (unsigned c0 = lane; c0 < ncand; c0 += 4 * kWave) {
+        double xs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned c = c0 + u * kWave;
+          xs[u] = sm.cand[c < ncand ? c : c0];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned c = c0 + u * kWave;
+          atomicAdd(&sm.hist[(key_of(xs[u]) - k1) >> sh], c < ncand ? one : 0u);  // past the end: add 0
+        }
+      }
       wave_sync();
       PLA_PHASE(5);
       int bstar = 0, C1 = 0;
@@ -489,15 +504,26 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         // ---- 4. candidates at/above the boundary bin -> sa, grouped by bin (descending bins) --------
         PLA_PHASE(6);
         const int kstar = k1 + (bstar << sh);
-        for (unsigned c = lane; c < ncand; c += kWave) {
-          const double x = sm.cand[c];
-          const int k = key_of(x);
-          if (k >= kstar) {
-            const int b = (k - k1) >> sh;
-            const unsigned slot = sm.start[b] + (atomicSub(&sm.hist[b], 1u) - 1u);
-            sm.sa[slot] = x;
+        for (unsigned c0 = lane; c0 < ncand; c0 += 4 * kWave) {
+          double xs[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned c = c0 + u * kWave;
+            xs[u] = sm.cand[c < ncand ? c : c0];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned c = c0 + u * kWave;
+            const double x = xs[u];
+            const int k = key_of(x);
+            if (c < ncand && k >= kstar) {
+              const int b = (k - k1) >> sh;
+              const unsigned slot = sm.start[b] + (atomicSub(&sm.hist[b], 1u) - 1u);
+              sm.sa[slot] = x;
+            }
           }
         }
+        if (lane < 4) sm.sa[C1 + lane] = -INF;  // sentinels for the 4-wide reads of the ranking loop
         wave_sync();
         PLA_PHASE(7);
         double* sb = sm.cand;  // the list is consumed: its storage now holds the sorted candidates
@@ -508,10 +534,17 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           const int lo = (int)sm.start[b];
           const int hi = (b > 0) ? (int)sm.start[b - 1] : C1;
           int cnt = 0, same = 0;
-          for (int c2 = lo; c2 < hi; ++c2) {
-            const double x2 = sm.sa[c2];
-            cnt += (x2 > x) ? 1 : 0;
-            same += (x2 == x) ? 1 : 0;  // counts the element itself
+          // four neighbours per trip (one LDS round trip): entries past the bin are smaller values of
+          // lower bins, entries past the end are -inf sentinels, so neither counts
+          for (int c2 = lo; c2 < hi; c2 += 4) {
+            double x2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x2[u] = sm.sa[c2 + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              cnt += (x2[u] > x) ? 1 : 0;
+              same += (x2[u] == x) ? 1 : 0;  // counts the element itself
+            }
           }
           if (__ballot(same > 1) != 0ull) {  // duplicates (repeated draws): order them by position
             if (same > 1)
@@ -534,19 +567,39 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           // (the reciprocals e^-x of the same range reduction are kept for the weight ratios below)
           double* inv_e = sb + kWaveCap + kWave;  // beyond the sorted candidates and the pair data
           const int n32 = (n + 31) & ~31;  // padded with y = 0 (factor 1) so that the fit runs whole trips only
-          for (int j = lane; j < n32; j += kWave) {
-            double ep, en;
-            exp_pair(sb[j < n ? n - 1 - j : 0], tb.tab, ep, en);
-            sm.sa[j] = j < n ? ep - e_cut : 0.0;
-            inv_e[j] = en;
-          }
+          // Straight-line code for 3 (n <= 192, the usual case) or 4 elements per lane: the independent
+          // exp chains interleave instead of running one LDS round trip + ~20 dependent fp64 ops at a time.
+          // Every slot up to 64 U is written (zeros past n), so the later loops need no bounds either.
+          const bool three = n32 <= 3 * kWave;
+          const auto y_pass = [&](auto UC) {
+            constexpr int U = decltype(UC)::value;
+            double xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const int j = lane + kWave * u;
+              xv[u] = sb[j < n ? n - 1 - j : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const int j = lane + kWave * u;
+              double ep, en;
+              exp_pair(xv[u], tb.tab, ep, en);
+              sm.sa[j] = j < n ? ep - e_cut : 0.0;
+              inv_e[j] = en;
+            }
+          };
+          if (three) y_pass(std::integral_constant<int, 3>{}); else y_pass(std::integral_constant<int, 4>{});
           wave_sync();
           const double* y = sm.sa;
           const double nn = (double)n;
           // (1 - b y0)(1 - b y1) = 1 - b (y0 + y1) + b^2 y0 y1: pair sums / products once per row
-          for (int p2 = lane; 2 * p2 < n32; p2 += kWave) {
-            const double2 yy = *reinterpret_cast<const double2*>(y + 2 * p2);
-            *reinterpret_cast<double2*>(&sb[2 * p2]) = make_double2(yy.x + yy.y, yy.x * yy.y);
+          {
+            double2 yy[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) yy[u] = *reinterpret_cast<const double2*>(y + 2 * (lane + kWave * u));
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+              *reinterpret_cast<double2*>(&sb[2 * (lane + kWave * u)]) = make_double2(yy[u].x + yy[u].y, yy[u].x * yy[u].y);
           }
           wave_sync();
           const double* yp = sb;
@@ -618,8 +671,13 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           const double b_post = (sw > 0.0) ? div_fast(bw, sw) : 0.0;                  // psis.py:198,201
           // psis.py:203: mean_i log1p(-b_post*y_i) as the log of per-lane products
           PLA_PHASE(12);
-          double pr = 1.0;
-          for (int ii = lane; ii < n; ii += kWave) pr *= fma(-b_post, y[ii], 1.0);
+          double pr;
+          {  // y is zero past n: no bounds
+            const double f0 = fma(-b_post, y[lane], 1.0), f1 = fma(-b_post, y[lane + kWave], 1.0);
+            const double f2 = fma(-b_post, y[lane + 2 * kWave], 1.0);
+            pr = f0 * f1 * f2;
+            if (!three) pr *= fma(-b_post, y[lane + 3 * kWave], 1.0);
+          }
           const double k_post = wave_all<R_SUM>(log_tab(pr, tb.lt)) * rn;
           const double sigma = -k_post / b_post;                                      // psis.py:205
           khat = (nn * k_post + 5.0) / (nn + 10.0);                                   // psis.py:206
@@ -629,21 +687,50 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
             smoothed = true;
             const double rk = 1.0 / khat;
             const bool ktiny = fabs(khat) < kEps;
-            for (int j = lane; j < n; j += kWave) {
-              // log1p(-p_j), p_j = (j + 0.5)/n (psis.py:153): host table when n == M
-              const double l1 = (n == M) ? l1tab[j] : log_fast(1.0 - ((double)j + 0.5) * rn);
-              double q;
-              if (sigma <= 0.0) {
-                q = qnan();                                                           // psis.py:214-215
-              } else {
-                q = ktiny ? -l1 : expm1_tab(-khat * l1, tb.tab) * rk;                 // psis.py:218-221
-                q *= sigma;
+            if (sigma > 0.0 && !ktiny && n == M) {
+              // the usual case, straight-line: w_j = sigma/k (e^{z_j} - 1) + e_cut with z_j = -k log1p(-p_j) from
+              // the host table (psis.py:153,218-221).  e^z - 1 by subtraction is accurate to 1e-16 ABSOLUTE,
+              // which is all the sum w_j + e_cut can see.
+              const double coef = sigma * rk, off = e_cut - coef;
+              const auto smooth_pass = [&](auto UC) {
+                constexpr int U = decltype(UC)::value;
+                double ez[U], yv[U], iv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                  const int j = lane + kWave * u;
+                  const double z = fmin(-khat * l1tab[j < n ? j : 0], 700.0);
+                  ez[u] = exp_tab(z, tb.tab);
+                  yv[u] = y[j];
+                  iv[u] = inv_e[j];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                  const int j = lane + kWave * u;
+                  double wj = fma(ez[u], coef, off);  // exp(log(q + e_cut)), psis.py:155
+                  wj = fmin(wj, 1.0);                 // psis.py:157
+                  const double ej = yv[u] + e_cut;
+                  acc_t += (j < n) ? wj - ej : 0.0;
+                  acc_r += (j < n) ? wj * iv[u] : 0.0;
+                }
+              };
+              if (three) smooth_pass(std::integral_constant<int, 3>{}); else smooth_pass(std::integral_constant<int, 4>{});
+            } else {
+              for (int j = lane; j < n; j += kWave) {
+                // log1p(-p_j), p_j = (j + 0.5)/n (psis.py:153): host table when n == M
+                const double l1 = (n == M) ? l1tab[j] : log_fast(1.0 - ((double)j + 0.5) * rn);
+                double q;
+                if (sigma <= 0.0) {
+                  q = qnan();                                                           // psis.py:214-215
+                } else {
+                  q = ktiny ? -l1 : expm1_tab(-khat * l1, tb.tab) * rk;                 // psis.py:218-221
+                  q *= sigma;
+                }
+                double wj = q + e_cut;   // exp(log(q + e_cut)), psis.py:155
+                if (wj > 1.0) wj = 1.0;  // psis.py:157
+                const double ej = y[j] + e_cut;
+                acc_t += wj - ej;
+                acc_r = fma(wj, inv_e[j], acc_r);
               }
-              double wj = q + e_cut;   // exp(log(q + e_cut)), psis.py:155
-              if (wj > 1.0) wj = 1.0;  // psis.py:157
-              const double ej = y[j] + e_cut;
-              acc_t += wj - ej;
-              acc_r = fma(wj, inv_e[j], acc_r);
             }
           }
         }
