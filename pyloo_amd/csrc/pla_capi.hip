@@ -411,6 +411,17 @@ int pla_importance_weights(pla_engine* eng, const void* logw, int dtype, int64_t
   p.tail_cap = pow2_at_least(p.tail_count);
   p.scale_value = 1.0;
   p.counters = eng->counters;
+  PLA_HIP(hipMemsetAsync(eng->counters, 0, 4 * sizeof(unsigned long long), s));
+  if (n_obs > 0) {  // workspace of the fast path (rows it declines, quantile tables)
+    rc = grow(&eng->d_slow, &eng->d_slow_bytes, (size_t)n_obs * sizeof(unsigned));
+    if (rc) return rc;
+    p.slow_list = (unsigned*)eng->d_slow;
+    if (method == PLA_PSIS) {
+      rc = ensure_l1_table(eng, tail_count, s);
+      if (rc) return rc;
+      p.l1_table = eng->d_l1;
+    }
+  }
 
   if (mem_space == PLA_DEVICE) {
     p.in = logw;

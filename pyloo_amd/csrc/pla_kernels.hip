@@ -42,7 +42,7 @@ __global__ __launch_bounds__(BLOCK) void rows_kernel(RowsParams P) {
 }
 
 // rows the fast kernel handed over: same general pipeline, row indices from the device list
-template <typename T, int BLOCK>
+template <typename T, int BLOCK, bool LW>
 __global__ __launch_bounds__(BLOCK) void slow_rows_kernel(RowsParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const Smem sm = carve<BLOCK>(smem_raw, P.tail_cap);
@@ -51,8 +51,8 @@ __global__ __launch_bounds__(BLOCK) void slow_rows_kernel(RowsParams P) {
   for (unsigned long long i = blockIdx.x; i < count; i += gridDim.x) {
     const int64_t r = (int64_t)P.slow_list[i];
     const T* rp = reinterpret_cast<const T*>(P.in) + r * P.stride_obs;
-    RowGlobal<T, true> row{rp, P.stride_draw, P.n_draws};
-    process_row<RowGlobal<T, true>, T, BLOCK, false>(row, P, sm, r);
+    RowGlobal<T, !LW> row{rp, P.stride_draw, P.n_draws};
+    process_row<RowGlobal<T, !LW>, T, BLOCK, LW>(row, P, sm, r);
   }
 }
 
@@ -213,7 +213,7 @@ static int debug_flag(const char* name) {
   return v ? atoi(v) : 0;
 }
 
-template <typename T, int VEC>
+template <typename T, int VEC, bool LW>
 static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
@@ -227,13 +227,13 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, hipStream_t 
   // 256 CUs (8 waves each) busy with a short tail
   int64_t grid = (p.n_obs + kWavesPerBlock - 1) / kWavesPerBlock;
   if (grid > 2048 * 8 / kWavesPerBlock) grid = 2048 * 8 / kWavesPerBlock;
-  hipLaunchKernelGGL((wave_loo_kernel<T, VEC>), dim3((unsigned)grid), dim3(kWave * kWavesPerBlock), 0, stream, p, f);
+  hipLaunchKernelGGL((wave_loo_kernel<T, VEC, LW>), dim3((unsigned)grid), dim3(kWave * kWavesPerBlock), 0, stream, p, f);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   // general kernel over whatever the fast path declined (usually nothing)
   constexpr int BLOCK = 256;
   int64_t g2 = p.n_obs < 1024 ? p.n_obs : 1024;
-  hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap),
+  hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK, LW>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap),
                      stream, p);
   return hipGetLastError();
 }
@@ -242,16 +242,17 @@ template <typename T, bool LW>
 static hipError_t launch_typed(const RowsParams& p, hipStream_t stream) {
   constexpr int BLOCK = 256;
   const bool unit = (p.stride_draw == 1);
-  if constexpr (!LW) {
+  {
     static const int path = debug_flag("PLA_FORCE_PATH");  // 0 auto, 1 general kernel only (tests)
     constexpr int WVEC = 16 / sizeof(T);
-    const bool waligned = ((uintptr_t)p.in % 16 == 0) && (p.stride_obs % WVEC == 0) && (p.n_draws % WVEC == 0);
+    bool waligned = ((uintptr_t)p.in % 16 == 0) && (p.stride_obs % WVEC == 0) && (p.n_draws % WVEC == 0);
+    if (LW) waligned = waligned && ((uintptr_t)p.lw_out % 16 == 0);  // rows of lw_out are n_draws apart
     if (path != 1 && unit && waligned && p.method == PLA_PSIS && p.slow_list && p.counters && p.l1_table &&
         p.n_draws <= kWave * kWaveSlots && p.n_draws >= 256 && p.tail_count <= kWaveMaxTail &&
         smem_bytes(BLOCK, p.tail_cap) <= 64 * 1024 && p.n_obs <= 0xffffffffll) {
       int gsz = 0, kq = 0;
       if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq)) {
-        return launch_wave<T, WVEC>(p, gsz, kq, stream);
+        return launch_wave<T, WVEC, LW>(p, gsz, kq, stream);
       }
     }
     if (path == 1) return launch_one<T, BLOCK, 0, LW>(p, stream);

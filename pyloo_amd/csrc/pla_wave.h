@@ -113,6 +113,11 @@ __device__ __forceinline__ double vmin_nc(double a, double b) {
   asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
+__device__ __forceinline__ float vmin_nc(float a, float b) {
+  float d;
+  asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 template <RedOp OP>
 __device__ __forceinline__ double red2(double a, double b) {
   if constexpr (OP == R_SUM) return a + b;
@@ -139,6 +144,13 @@ struct WaveSmem {
   double cand[kCandCap + 2 * kWave];  // candidate x values (+ 64 overflow slots + one dump slot per lane); reused for the
                                     // candidates sorted descending once they are binned
   double sa[kWaveCap + 4];          // candidates at/above the boundary bin, grouped by bin (+ 4 sentinels); later y ascending
+};
+// weights mode (psislw): the candidates carry their draw index so that the smoothed tail can be
+// written back to its positions
+struct WaveSmemLW : WaveSmem {
+  unsigned short ids[kCandCap + 2 * kWave];  // draw index of cand[c]
+  unsigned short sa_id[kWaveCap + 4];        // ... of sa[c]
+  unsigned short sb_id[kWaveCap];            // ... of the sorted candidates
 };
 // read-only tables shared by the waves of a workgroup
 struct WaveTables {
@@ -238,8 +250,11 @@ __device__ __forceinline__ void pad_tail(T (&v)[kWaveSlots], int qfull, int qrem
   }
 }
 
-template <typename T, int VEC>
-__device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParams& F, WaveSmem& sm, const WaveTables& tb, const int64_t r,
+// LW = false: LOO mode (input = log-likelihood, raw = -ll; outputs k-hat, loo_i, lppd_i)
+// LW = true:  weights mode (input = log ratios, raw = input; outputs k-hat and the normalised smoothed
+//             log-weights, psis.py:78-111): the row stays in its registers until the weights are stored
+template <typename T, int VEC, bool LW, typename SM>
+__device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParams& F, SM& sm, const WaveTables& tb, const int64_t r,
                                             T (&v)[kWaveSlots], const T* rp_next) {
   constexpr int EPT = kWaveSlots;
   constexpr int NQ = EPT / VEC;
@@ -275,11 +290,11 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   double mx, mn, gs;
   {
     const T ninf = (T)(-INF);
-    T cur = ninf, vmx = ninf, snap = ninf;
+    T cur = ninf, vmx = LW ? (T)INF : ninf, snap = ninf;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
-      cur = vmax_nc<true>(v[i], cur);
-      vmx = vmax_nc<false>(v[i], vmx);
+      cur = vmax_nc<!LW>(v[i], cur);                            // max raw
+      vmx = LW ? vmin_nc(v[i], vmx) : vmax_nc<false>(v[i], vmx);  // min raw (LOO: as max ll)
       if ((i == 3 || i == 7 || i == 15 || i == 31) && i < EPT) {  // gsz is one of 4, 8, 16, 32 (wave_threshold_params)
         if (gsz == i + 1) {
           asm volatile("");  // a real wave-uniform branch, not a select per slot
@@ -288,7 +303,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       }
     }
     mx = (double)cur;
-    mn = -(double)vmx;
+    mn = LW ? (double)vmx : -(double)vmx;
     gs = (double)snap;
   }
   const double m = wave_all<R_MAX>(mx);
@@ -337,7 +352,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       for (int i = 0; i < kWaveBins / (4 * kWave); ++i) *reinterpret_cast<uint4*>(&sm.hist[4 * (lane + kWave * i)]) = z4;
     }
     // pads: rewrite invalid vectors to ll = -mn  (raw = mn, x = -R)
-    const T padv = (T)(-mn);
+    const T padv = LW ? (T)mn : (T)(-mn);
     pad_tail<T, VEC, NQ - 1, true>(v, qfull, qrem, padv);
     wave_sync();
     // ---- 2. sweep: e^x and e^-x of every draw from one range reduction + histogram of candidates ----
@@ -352,9 +367,12 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     int four = 4;
     asm volatile("" : "+v"(four));
     // the next row (a zero-length range when there is none: the loads then return zeros and touch nothing)
+    // (weights mode streams the SAME row in again: its raw values are needed once more for the final
+    // pass, and holding them through selection and fit would spill)
+    const T* rp_stream = LW ? reinterpret_cast<const T*>(P.in) + r * P.stride_obs : rp_next;
     const __amdgpu_buffer_rsrc_t rs_next = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>(rp_next ? rp_next : (const T*)P.in), 0, rp_next ? S * (int)sizeof(T) : 0, 0x00020000);
-    streamed = true;
+        const_cast<T*>(rp_stream ? rp_stream : (const T*)P.in), 0, rp_stream ? S * (int)sizeof(T) : 0, 0x00020000);
+    streamed = !LW;  // weights mode: the next row is requested after the weights have been stored
     const char* tabc = reinterpret_cast<const char*>(tb.tab);
     // The candidate list is addressed with raw LDS byte addresses so that this wave's scratch base
     // rides in the scalar append offset / the precomputed dump address instead of costing a vector
@@ -390,7 +408,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       }
       if (i < EPT) {  // stage A of draw i: 8 VALU
         const int sl = i % kPF;
-        const double x = (-(double)v[i]) - m;  // psis.py:134
+        const double x = LW ? (double)v[i] - m : (-(double)v[i]) - m;  // psis.py:134
         const double t = fma(x, c256, magic);
         const int k = __double2loint(t);       // round(x * 256/ln2): low mantissa bits of t
         px[sl] = x;
@@ -406,6 +424,9 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         unsigned pos8 = (rank << 3) + base8;
         asm("" : "+v"(pos8));  // computed by every lane: a select below, not a divergent region
         lds_store(cand ? pos8 : dump8, x);
+        if constexpr (LW)  // draw index of the candidate: VEC * (lane + 64 q) + e for slot i = q VEC + e
+          sm.ids[cand ? ((pos8 - cand0) >> 3) : (unsigned)(kCandCap + kWave + lane)] =
+              (unsigned short)(VEC * lane + (VEC * kWave * (i / VEC) + i % VEC));
         {  // next8 += 8 * popcount(cm) in two scalar ops (the compiler would re-associate it into four)
           const unsigned pc = (unsigned)__popcll(cm);
           asm("s_lshl3_add_u32 %0, %1, %0" : "+s"(next8) : "s"(pc) : "scc");
@@ -472,12 +493,17 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           c[4 * i] = h.x; c[4 * i + 1] = h.y; c[4 * i + 2] = h.z; c[4 * i + 3] = h.w;
           tot += h.x + h.y + h.z + h.w;
         }
-        unsigned suf = tot;
-#pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-          const unsigned t = (unsigned)__shfl_down((int)suf, o);
-          if (lane + o < kWave) suf += t;
-        }
+        // inclusive prefix sum over the 64 lanes with DPP adds (no LDS round trips), then suffix = total - prefix
+        unsigned pre = tot;
+        pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)tot, 0x111, 0xF, 0xF, true);   // row_shr:1
+        pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)tot, 0x112, 0xF, 0xF, true);   // row_shr:2
+        pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)tot, 0x113, 0xF, 0xF, true);   // row_shr:3
+        pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x114, 0xF, 0xE, false);  // row_shr:4, banks 1-3
+        pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x118, 0xF, 0xC, false);  // row_shr:8, banks 2-3
+        pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x142, 0xA, 0xF, false);  // row_bcast:15
+        pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x143, 0xC, 0xF, false);  // row_bcast:31
+        const unsigned all = (unsigned)__builtin_amdgcn_readlane((int)pre, kWave - 1);
+        const unsigned suf = all - pre + tot;  // this lane's bins and everything above
         unsigned a = suf - tot;  // candidates in bins owned by higher lanes
         int fb = -1, fc = 0;
         unsigned st[8];
@@ -511,6 +537,14 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
             const unsigned c = c0 + u * kWave;
             xs[u] = sm.cand[c < ncand ? c : c0];
           }
+          unsigned short idv[4] = {0, 0, 0, 0};
+          if constexpr (LW) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const unsigned c = c0 + u * kWave;
+              idv[u] = sm.ids[c < ncand ? c : c0];
+            }
+          }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const unsigned c = c0 + u * kWave;
@@ -520,6 +554,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
               const int b = (k - k1) >> sh;
               const unsigned slot = sm.start[b] + (atomicSub(&sm.hist[b], 1u) - 1u);
               sm.sa[slot] = x;
+              if constexpr (LW) sm.sa_id[slot] = idv[u];
             }
           }
         }
@@ -551,6 +586,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
               for (int c2 = lo; c2 < c; ++c2) cnt += (sm.sa[c2] == x) ? 1 : 0;
           }
           sb[lo + cnt] = x;
+          if constexpr (LW) sm.sb_id[lo + cnt] = sm.sa_id[c];
         }
         wave_sync();
         // ---- cutoff (psis.py:135-141); R < 690: the log(DBL_MIN) floor cannot bind -------------
@@ -614,7 +650,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           b = div_fast(b, 3.0 * yq);   // psis.py:187
           b += recip_fast(yn);         // psis.py:188
           const double b_first = lane_value(b, 0);  // most negative grid point
-          const double b_last = uniform_d(__shfl(b, mest - 1));
+          const double b_last = lane_value(b, mest - 1);
           const double fbig = fma(-b_first, yn, 1.0), fsmall = fma(-b_last, yn, 1.0);
           const bool wide = (fbig < 0x1p30) && (fsmall > 0x1p-30);  // 16 factors per accumulator between renorms
           // lanes whose b_j is ~0 would lose the low bits of b_j*y in 1 - b_j*y: carry them along
@@ -684,6 +720,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
           PLA_PHASE(13);
           if (isfinite(khat)) {
             const double* inv_e = sb + kWaveCap + kWave;
+            double* wtail = sb + kWaveCap + kWave;  // weights mode: overwrites inv_e (not needed there)
             smoothed = true;
             const double rk = 1.0 / khat;
             const bool ktiny = fabs(khat) < kEps;
@@ -711,6 +748,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
                   const double ej = yv[u] + e_cut;
                   acc_t += (j < n) ? wj - ej : 0.0;
                   acc_r += (j < n) ? wj * iv[u] : 0.0;
+                  if constexpr (LW) wtail[j] = wj;  // (clipped) smoothed weight of tail element j
                 }
               };
               if (three) smooth_pass(std::integral_constant<int, 3>{}); else smooth_pass(std::integral_constant<int, 4>{});
@@ -730,6 +768,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
                 const double ej = y[j] + e_cut;
                 acc_t += wj - ej;
                 acc_r = fma(wj, inv_e[j], acc_r);
+                if constexpr (LW) wtail[j] = wj;
               }
             }
           }
@@ -737,15 +776,50 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         // total = sum_nontail e^x + sum_tail w' = (s1 - sum_tail e) + sum_tail w'
         PLA_PHASE(14);
         const double total = wave_all<R_SUM>(s1 + acc_t);
-        s2 = wave_all<R_SUM>(s2);
-        // loo_i = -m - L + log(tail_ratio),  L = log(total) (psis.py:158; loo.py:289,319-324): one log
-        double tail_ratio = (double)S;
-        if (smoothed) tail_ratio = (double)(S - n) + wave_all<R_SUM>(acc_r);
-        // the two logs of the row in one call: lane 1 takes s2, every other lane the weight ratio
-        const double lg = log_tab(lane == 1 ? s2 : div_fast(tail_ratio, total), tb.lt);
-        loo = lane_value(lg, 0) - m;
-        lppd = (lane_value(lg, 1) - R) + ((-mn) - logS);                      // loo.py:329-337
-        if ((!(total > 1e-280) || !isfinite(loo) || !isfinite(lppd)) && !(dbgs & 63)) slow = true;
+        if constexpr (LW) {
+          // ---- weights mode: lw_s = x_s - log(total) for every draw, the smoothed tail at its positions ----
+          const double L = log_tab(total, tb.lt);  // psis.py:158 (_logsumexp of the shifted, smoothed row)
+          if (!(total > 1e-280) || !isfinite(L)) {
+            slow = true;
+          } else {
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            T* orow = reinterpret_cast<T*>(P.lw_out) + r * (int64_t)S;
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(orow, 0, S * (int)sizeof(T), 0x00020000);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+              if (q <= qfull) {  // later vectors lie past the row (stores past the end are dropped anyway)
+                v4i t;
+                if constexpr (VEC == 2) {
+                  const double a0 = ((double)v[2 * q] - m) - L, a1 = ((double)v[2 * q + 1] - m) - L;
+                  t[0] = __double2loint(a0); t[1] = __double2hiint(a0);
+                  t[2] = __double2loint(a1); t[3] = __double2hiint(a1);
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) t[e] = __float_as_int((float)(((double)v[4 * q + e] - m) - L));
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(t, ro, lane * 16, q * (kWave * 16), 0);
+              }
+            }
+            if (smoothed) {
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the patches below must land after the row
+              const double* wtail = sb + kWaveCap + kWave;
+              for (int j = lane; j < n; j += kWave) {
+                const int id = (int)sm.sb_id[n - 1 - j];
+                orow[id] = (T)(log_tab(wtail[j], tb.lt) - L);  // psis.py:155-158
+              }
+            }
+          }
+        } else {
+          s2 = wave_all<R_SUM>(s2);
+          // loo_i = -m - L + log(tail_ratio),  L = log(total) (psis.py:158; loo.py:289,319-324): one log
+          double tail_ratio = (double)S;
+          if (smoothed) tail_ratio = (double)(S - n) + wave_all<R_SUM>(acc_r);
+          // the two logs of the row in one call: lane 1 takes s2, every other lane the weight ratio
+          const double lg = log_tab(lane == 1 ? s2 : div_fast(tail_ratio, total), tb.lt);
+          loo = lane_value(lg, 0) - m;
+          lppd = (lane_value(lg, 1) - R) + ((-mn) - logS);                      // loo.py:329-337
+          if ((!(total > 1e-280) || !isfinite(loo) || !isfinite(lppd)) && !(dbgs & 63)) slow = true;
+        }
       }
     }
   }
@@ -759,8 +833,10 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       F.slow_list[idx] = (unsigned)r;
     } else {
       if (P.diag) P.diag[r] = khat;
-      if (P.loo_i) P.loo_i[r] = P.scale_value * loo;
-      if (P.lppd_i) P.lppd_i[r] = lppd;
+      if constexpr (!LW) {
+        if (P.loo_i) P.loo_i[r] = P.scale_value * loo;
+        if (P.lppd_i) P.lppd_i[r] = lppd;
+      }
     }
   }
 }
@@ -768,9 +844,10 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
 // The per-row body is deliberately NOT inlined into the row loop: inlined, LLVM hoists every
 // loop-invariant constant, mask and offset of the later phases above the loop, where they sit on
 // top of the 128 row registers and spill.
-template <typename T, int VEC>
+template <typename T, int VEC, bool LW>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, PLA_MIN_WAVES_PER_SIMD) void wave_loo_kernel(RowsParams P, FastParams F) {
-  __shared__ __attribute__((aligned(16))) WaveSmem scratch[kWavesPerBlock];
+  using SM = std::conditional_t<LW, WaveSmemLW, WaveSmem>;
+  __shared__ __attribute__((aligned(16))) SM scratch[kWavesPerBlock];
   __shared__ __attribute__((aligned(16))) WaveTables tb;
   const int tid = threadIdx.x;
   for (int j = tid; j < kTabN; j += kWave * kWavesPerBlock) exp_table_entry(tb.tab, j);
@@ -779,7 +856,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, PLA_MIN_WAVES_PER_SIMD) voi
   if (tid < kWave) tb.bg[tid] = F.b_grid[tid];
   __syncthreads();  // the only workgroup barrier: from here on the waves are independent
   const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);  // wave-uniform, and the compiler knows it
-  WaveSmem& sm = scratch[wv];
+  SM& sm = scratch[wv];
   T v[kWaveSlots];
   const T* base = reinterpret_cast<const T*>(P.in);
   const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + wv, nw = (int64_t)gridDim.x * kWavesPerBlock;
@@ -790,7 +867,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, PLA_MIN_WAVES_PER_SIMD) voi
 #endif
   for (int64_t r = w0; r < P.n_obs; r += nw) {
     const int64_t rn = r + nw;
-    wave_loo_row<T, VEC>(P, F, sm, tb, r, v, rn < P.n_obs ? base + rn * P.stride_obs : nullptr);
+    wave_loo_row<T, VEC, LW, SM>(P, F, sm, tb, r, v, rn < P.n_obs ? base + rn * P.stride_obs : nullptr);
   }
 #if PLA_WAVE_ABLATE
   if (blockIdx.x == 0 && tid == 0) {  // core clock against the 100 MHz real-time counter

@@ -274,6 +274,77 @@ def test_fast_and_slow_rows_in_one_matrix(eng):
     assert int(res["agg"][5]) == int(np.sum(~np.isfinite(ref["khat"])))
 
 
+def test_weights_fast_and_slow_rows_in_one_matrix(eng):
+    """psislw through the wave kernel (weights mode) with rows it has to hand to the general kernel mixed
+    in: every row's smoothed log-weights and k-hat equal the oracle; f32 keeps its dtype."""
+    rng = np.random.default_rng(515)
+    N, S = 200, 4000
+    k = rng.uniform(0.05, 1.3, size=N)
+    logw = k[:, None] * rng.exponential(size=(N, S)) + rng.normal(size=(N, 1))
+    logw[5, 3] = -np.inf                  # weight 0 for one draw
+    logw[9, 100] = np.nan                 # NaN row: k = inf, NaN weights
+    logw[31] = 1.25                       # constant row
+    logw[64] *= 500.0                     # range above 690 nats
+    logw[120] = np.round(logw[120] * 8.0) / 8.0   # coarse grid: ties inside the tail
+    lw_ref, k_ref = orc.psislw(logw, 1.0)
+    lw, kk = eng.importance_weights(logw, 190, "psis")
+    close(kk, k_ref, what="khat")
+    tied = [i for i in range(N) if has_tail_ties(-logw[i], 190)]
+    a, b = lw.copy(), lw_ref.copy()
+    for i in tied:
+        a[i], b[i] = np.sort(a[i]), np.sort(b[i])
+    close(a, b, what="lw")
+    ok = np.isfinite(k_ref)
+    np.testing.assert_allclose(np.exp(lw[ok]).sum(axis=1), 1.0, rtol=1e-12)
+    # S not a multiple of 64 lanes x 16 bytes: partial last vector
+    logw2 = logw[:40, :3998].copy()
+    lw2_ref, k2_ref = orc.psislw(logw2, 1.0)
+    lw2, k2 = eng.importance_weights(logw2, orc.tail_count(3998, 1.0), "psis")
+    close(k2, k2_ref, what="khat(3998)")
+    t2 = [i for i in range(40) if has_tail_ties(-logw2[i], orc.tail_count(3998, 1.0))]
+    for i in t2:
+        lw2[i], lw2_ref[i] = np.sort(lw2[i]), np.sort(lw2_ref[i])
+    close(lw2, lw2_ref, what="lw(3998)")
+    # f32 in, f32 out
+    l32 = logw[:64].astype(np.float32)
+    ok32 = np.isfinite(l32).all(axis=1)
+    lw32, k32 = eng.importance_weights(l32, 190, "psis")
+    assert lw32.dtype == np.float32
+    ref32, kref32 = orc.psislw(l32.astype(np.float64), 1.0)
+    close(k32, kref32, what="khat(f32)")
+    t32 = [i for i in range(64) if has_tail_ties(-l32[i].astype(np.float64), 190)]
+    a32, b32 = lw32.copy(), ref32.astype(np.float32)
+    for i in t32:
+        a32[i], b32[i] = np.sort(a32[i]), np.sort(b32[i])
+    close(a32, b32, rtol=2e-7, atol=1e-6, what="lw(f32)")
+
+
+def test_weights_device_tensors_full_size(eng):
+    """Weights mode on a device-resident matrix (S=4000 x N=20k): normalised rows, k-hat equal to the LOO
+    pass on the negated matrix, bitwise reproducible."""
+    import torch
+
+    S, N = 4000, 20_000
+    ll = torch.empty((N, S), dtype=torch.float64, device="cuda")
+    eng.fill_synthetic(ll, seed=0x5EED0002)
+    logw = -ll
+    lw, k = eng.importance_weights(logw, 190, "psis")
+    lw_b, k_b = eng.importance_weights(logw, 190, "psis")
+    res = eng.psis_loo(ll, 190, "psis", 1.0, 0.7)
+    torch.cuda.synchronize()
+    assert torch.equal(lw, lw_b) and torch.equal(k, k_b)
+    np.testing.assert_allclose(k.cpu().numpy(), res["diag"].cpu().numpy(), rtol=1e-12)
+    sums = torch.exp(lw).sum(dim=1).cpu().numpy()
+    np.testing.assert_allclose(sums, 1.0, rtol=1e-12)
+    # loo_i recomputed from the returned weights (loo.py:289,319-324) equals the fused pass
+    loo_from_w = torch.logsumexp(lw + ll, dim=1).cpu().numpy()
+    np.testing.assert_allclose(loo_from_w, res["loo_i"].cpu().numpy(), rtol=1e-9, atol=1e-10)
+    idx = np.arange(0, N, 499)
+    ref_lw, ref_k = orc.psislw(logw[idx].cpu().numpy(), 1.0)
+    close(k.cpu().numpy()[idx], ref_k, what="khat")
+    close(lw.cpu().numpy()[idx], ref_lw, what="lw")
+
+
 def test_general_kernel_agrees_with_fast_path():
     """Same matrix through the wave kernel and (in a child process) through the general kernel only."""
     import subprocess
