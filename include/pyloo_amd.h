@@ -122,6 +122,26 @@ int pla_reduce_pointwise(pla_engine *eng, const double *diag, const double *loo_
                          const double *lppd_i, int64_t n_obs, double good_k, int mem_space,
                          void *stream, double *agg);
 
+/*
+ * pla_waic -- the WAIC pass: one read of the matrix.
+ * Replaces waic.py:109-160: NaN -> -1e10 and +-inf -> +-1e10 on load (112-135),
+ * lppd_i = LSE_s(ll) - log S (137-143, utils.py:305-359), var_i = population variance over draws (145),
+ * waic_i = scale * (lppd_i - var_i) (158) and the sums of 159-161.
+ *
+ *   lppd_i, var_i, waic_i   [n_obs] double, each may be NULL
+ *   agg  [PLA_AGG_COUNT] may be NULL, slots reused as
+ *        PLA_AGG_N          n
+ *        PLA_AGG_SUM_LOO    sum_i waic_i            (elpd_waic, waic.py:160)
+ *        PLA_AGG_M2_LOO     sum_i (waic_i - mean)^2 (se = sqrt(M2), waic.py:159)
+ *        PLA_AGG_SUM_LPPD   sum_i var_i             (p_waic, waic.py:161)
+ *        PLA_AGG_N_HIGH     #(var_i > 0.4)          (warning, waic.py:147)
+ *        PLA_AGG_MIN_DIAG   min_i var_i
+ *        PLA_AGG_N_SLOW     entries replaced on load (NaN or +-inf: the front's two warnings)
+ */
+int pla_waic(pla_engine *eng, const void *ll, int dtype, int64_t n_obs, int64_t n_draws,
+             int64_t stride_obs, int64_t stride_draw, double scale_value, int mem_space, void *stream,
+             double *lppd_i, double *var_i, double *waic_i, double *agg);
+
 /* Timing of the dominant kernel, measured with hipEvents on the launch stream.
  * enable != 0 brackets every main-kernel launch with events; pla_engine_kernel_ms returns the
  * accumulated milliseconds and launch count since the last call (it synchronises the events). */

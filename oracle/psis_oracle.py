@@ -228,3 +228,37 @@ def loo_arrays(ll, reff=1.0, scale_value=1):
     out = loo_aggregate(pw["loo_i"], pw["lppd_i"], pw["diag"], ll.shape[1], scale_value)
     out.update(khat=pw["diag"], loo_i=scale_value * pw["loo_i"], lppd_i=pw["lppd_i"], lw=pw["lw"])
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# WAIC (waic.py:109-160)
+# ---------------------------------------------------------------------------------------------
+def waic_sanitize(ll):
+    """waic.py:112-135: NaN -> -1e10, +inf -> 1e10, -inf -> -1e10 (returns a copy and the two flags)."""
+    ll = np.array(ll, dtype=np.float64, copy=True)
+    has_nan, has_inf = bool(np.isnan(ll).any()), bool(np.isinf(ll).any())
+    ll[np.isnan(ll)] = -1e10
+    ll = np.where(np.isinf(ll), np.where(ll > 0, 1e10, -1e10), ll)
+    return ll, has_nan, has_inf
+
+
+def waic_arrays(ll, scale_value=1):
+    """waic.py:137-161 on an (n_obs, n_draws) matrix: per-observation lppd_i (``_logsumexp`` with
+    ``b_inv = n_samples``, one call per observation as ``wrap_xarray_ufunc`` does), the population
+    variance over draws (xarray ``.var`` = ``np.var``, ddof 0), waic_i and the summaries."""
+    ll, has_nan, has_inf = waic_sanitize(ll)
+    n, s = ll.shape
+    lppd_i = np.array([lse(r, b_inv=s) for r in ll], dtype=np.float64).reshape(n)   # waic.py:137-143
+    vars_lpd = ll.var(axis=-1)                                                       # waic.py:145
+    waic_i = scale_value * (lppd_i - vars_lpd)                                       # waic.py:158
+    return {
+        "lppd_i": lppd_i,
+        "var_i": vars_lpd,
+        "waic_i": waic_i,
+        "elpd_waic": np.sum(waic_i),                                                 # waic.py:160
+        "se": (n * np.var(waic_i)) ** 0.5,                                           # waic.py:159
+        "p_waic": np.sum(vars_lpd),                                                  # waic.py:161
+        "warning": bool(np.any(vars_lpd > 0.4)),                                     # waic.py:147
+        "has_nan": has_nan,
+        "has_inf": has_inf,
+    }

@@ -7,6 +7,8 @@ from .elpd import ELPDData
 from .loo import loo, loo_from_matrix
 from .psis import psislw
 from .rcparams import rcParams
+from .waic import waic, waic_from_matrix
 
-__all__ = ["ISMethod", "ELPDData", "compute_importance_weights", "loo", "loo_from_matrix", "psislw", "rcParams"]
+__all__ = ["ISMethod", "ELPDData", "compute_importance_weights", "loo", "loo_from_matrix", "psislw", "rcParams", "waic",
+           "waic_from_matrix"]
 __version__ = "0.1.0"

@@ -474,6 +474,83 @@ int pla_importance_weights(pla_engine* eng, const void* logw, int dtype, int64_t
   return PLA_OK;
 }
 
+int pla_waic(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int64_t n_draws, int64_t stride_obs,
+             int64_t stride_draw, double scale_value, int mem_space, void* stream, double* lppd_i, double* var_i,
+             double* waic_i, double* agg) {
+  int rc = check_common(eng, ll, dtype, n_obs, n_draws, stride_obs, stride_draw, PLA_SIS, 0, mem_space);
+  if (rc) return rc;
+  PLA_HIP(hipSetDevice(eng->device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t esz = dtype == PLA_F64 ? 8 : 4;
+  PLA_HIP(hipMemsetAsync(eng->counters, 0, 4 * sizeof(unsigned long long), s));  // [1]: replaced entries
+
+  if (mem_space == PLA_DEVICE) {
+    double *dl = lppd_i, *dv = var_i, *dw = waic_i;
+    if (agg && (!dv || !dw)) {  // the aggregates need var_i and waic_i: engine scratch when not asked for
+      size_t have_b = eng->d_pw_elems * sizeof(double);
+      rc = grow((void**)&eng->d_pw, &have_b, (size_t)(3 * n_obs + PLA_AGG_COUNT) * sizeof(double));
+      eng->d_pw_elems = have_b / sizeof(double);
+      if (rc) return rc;
+      if (!dv) dv = eng->d_pw;
+      if (!dw) dw = eng->d_pw + n_obs;
+    }
+    {
+      TimedLaunch t(eng, s);
+      PLA_HIP(pla::launch_waic(ll, dtype, n_obs, (int)n_draws, stride_obs, stride_draw, scale_value, dl, dv, dw,
+                               eng->counters + 1, s));
+    }
+    if (agg) {
+      pla::ReduceParams rp{dv, dw, dv, n_obs, 0.4, agg, eng->counters + 1};  // waic.py:147 threshold
+      PLA_HIP(pla::launch_reduce(rp, eng->d_red, s));
+    }
+    return PLA_OK;
+  }
+
+  if (stride_draw != 1) return fail(PLA_ERR_UNSUPPORTED, "PLA_HOST input needs stride_draw == 1 (transpose on the host)");
+  {
+    size_t have_b = eng->d_pw_elems * sizeof(double);
+    rc = grow((void**)&eng->d_pw, &have_b, (size_t)(3 * n_obs + PLA_AGG_COUNT) * sizeof(double));
+    eng->d_pw_elems = have_b / sizeof(double);
+    if (rc) return rc;
+  }
+  double* dl = eng->d_pw;
+  double* dv = eng->d_pw + n_obs;
+  double* dw = eng->d_pw + 2 * n_obs;
+  double* dagg = eng->d_pw + 3 * n_obs;
+  const size_t row_bytes = (size_t)n_draws * esz;
+  int64_t rows_per_chunk = (int64_t)(((size_t)1 << 30) / (row_bytes ? row_bytes : 1));
+  if (rows_per_chunk < 1) rows_per_chunk = 1;
+  if (rows_per_chunk > n_obs) rows_per_chunk = n_obs;
+  if (n_obs > 0) {
+    rc = grow(&eng->d_in, &eng->d_in_bytes, (size_t)rows_per_chunk * row_bytes);
+    if (rc) return rc;
+  }
+  for (int64_t r0 = 0; r0 < n_obs; r0 += rows_per_chunk) {
+    const int64_t nr = (n_obs - r0 < rows_per_chunk) ? (n_obs - r0) : rows_per_chunk;
+    const char* src = (const char*)ll + (size_t)r0 * stride_obs * esz;
+    PLA_HIP(hipMemcpy2DAsync(eng->d_in, row_bytes, src, (size_t)stride_obs * esz, row_bytes, (size_t)nr,
+                             hipMemcpyHostToDevice, s));
+    {
+      TimedLaunch t(eng, s);
+      PLA_HIP(pla::launch_waic(eng->d_in, dtype, nr, (int)n_draws, n_draws, 1, scale_value, dl + r0, dv + r0, dw + r0,
+                               eng->counters + 1, s));
+    }
+    PLA_HIP(hipStreamSynchronize(s));  // the staging buffer is reused by the next chunk
+  }
+  if (n_obs > 0) {
+    if (lppd_i) PLA_HIP(hipMemcpyAsync(lppd_i, dl, n_obs * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (var_i) PLA_HIP(hipMemcpyAsync(var_i, dv, n_obs * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (waic_i) PLA_HIP(hipMemcpyAsync(waic_i, dw, n_obs * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  if (agg) {
+    pla::ReduceParams rp{dv, dw, dv, n_obs, 0.4, dagg, eng->counters + 1};
+    PLA_HIP(pla::launch_reduce(rp, eng->d_red, s));
+    PLA_HIP(hipMemcpyAsync(agg, dagg, PLA_AGG_COUNT * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  PLA_HIP(hipStreamSynchronize(s));
+  return PLA_OK;
+}
+
 int pla_fill_synthetic(pla_engine* eng, void* ll_device, int dtype, int64_t n_obs, int64_t n_draws, int64_t row0,
                        uint64_t seed, double k_lo, double k_hi, double heavy_lo, double heavy_hi, void* stream) {
   if (!eng) return fail(PLA_ERR_ARG, "engine is NULL");

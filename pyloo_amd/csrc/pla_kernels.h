@@ -42,6 +42,10 @@ int reduce_workspace_doubles();  // size of `workspace` (device memory)
 hipError_t launch_fill_synthetic(void* ll, int dtype, int64_t n_obs, int64_t n_draws, int64_t row0,
                                  uint64_t seed, double k_lo, double k_hi, double heavy_lo,
                                  double heavy_hi, hipStream_t stream);
+// WAIC pass (waic.py:109-160): lppd_i, var_i, waic_i per observation; `replaced` counts NaN/inf entries
+hipError_t launch_waic(const void* in, int dtype, int64_t n_obs, int n_draws, int64_t stride_obs, int64_t stride_draw,
+                       double scale_value, double* lppd_i, double* var_i, double* waic_i,
+                       unsigned long long* replaced, hipStream_t stream);
 // largest tail count the kernels accept
 int max_tail_count();
 

@@ -18,6 +18,7 @@
 #include "pla_fast.h"
 #include "pla_rows.h"
 #include "pla_wave.h"
+#include "pla_waic.h"
 
 namespace pla {
 
@@ -265,6 +266,31 @@ hipError_t launch_rows(const RowsParams& p, int dtype, bool lw_mode, hipStream_t
   if (p.n_obs <= 0) return hipSuccess;
   if (dtype == PLA_F64) return lw_mode ? launch_typed<double, true>(p, stream) : launch_typed<double, false>(p, stream);
   return lw_mode ? launch_typed<float, true>(p, stream) : launch_typed<float, false>(p, stream);
+}
+
+template <typename T>
+static hipError_t launch_waic_typed(const WaicParams& p, hipStream_t stream) {
+  constexpr int WVEC = 16 / sizeof(T);
+  const bool fast = p.stride_draw == 1 && ((uintptr_t)p.in % 16 == 0) && (p.stride_obs % WVEC == 0) &&
+                    (p.n_draws % WVEC == 0) && p.n_draws <= kWave * kWaveSlots && p.n_draws >= kWave * WVEC;
+  static const int path = debug_flag("PLA_FORCE_PATH");
+  if (fast && path != 1) {
+    int64_t grid = (p.n_obs + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (grid > 2048 * 8 / kWavesPerBlock) grid = 2048 * 8 / kWavesPerBlock;
+    hipLaunchKernelGGL((waic_wave_kernel<T, WVEC>), dim3((unsigned)grid), dim3(kWave * kWavesPerBlock), 0, stream, p);
+  } else {
+    int64_t grid = p.n_obs < 8192 ? p.n_obs : 8192;
+    hipLaunchKernelGGL((waic_rows_kernel<T, 256>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_waic(const void* in, int dtype, int64_t n_obs, int n_draws, int64_t stride_obs, int64_t stride_draw,
+                       double scale_value, double* lppd_i, double* var_i, double* waic_i,
+                       unsigned long long* replaced, hipStream_t stream) {
+  if (n_obs <= 0) return hipSuccess;
+  WaicParams p{in, n_obs, n_draws, stride_obs, stride_draw, scale_value, lppd_i, var_i, waic_i, replaced};
+  return dtype == PLA_F64 ? launch_waic_typed<double>(p, stream) : launch_waic_typed<float>(p, stream);
 }
 
 int reduce_workspace_doubles() { return kRedChunks * kRedSlots; }

@@ -1,0 +1,183 @@
+// WAIC kernels (reference: pyloo waic.py:109-160).  Per observation, from ONE read of its row of S
+// log-likelihood draws:
+//   lppd_i = logsumexp_s(ll) - log S              (waic.py:137-143, utils.py:305-359 with b_inv = S)
+//   var_i  = population variance of ll over draws (waic.py:145, two-pass like np.var)
+//   waic_i = scale * (lppd_i - var_i)             (waic.py:158)
+// NaN -> -1e10 and +-inf -> +-1e10 are applied on load exactly as the reference front does before the
+// arithmetic (waic.py:112-135); the number of replaced entries is counted so that the front can emit
+// the reference's warnings.
+//
+// waic_wave_kernel: one wavefront per observation, the row in its registers (S <= 4096, unit draw stride,
+// 16-byte aligned rows) -- one HBM read, everything else in registers; the next row streams into the
+// registers the second pass has consumed (64 * 16/sizeof(T) <= S).  waic_rows_kernel: any shape / stride, one workgroup per
+// observation, three passes over the (L2-resident) row.
+#pragma once
+
+#include "pla_wave.h"
+
+namespace pla {
+
+struct WaicParams {
+  const void* in;
+  int64_t n_obs;
+  int n_draws;
+  int64_t stride_obs, stride_draw;  // elements
+  double scale_value;
+  double* lppd_i;   // [n_obs] or null
+  double* var_i;    // [n_obs] or null
+  double* waic_i;   // [n_obs] or null
+  unsigned long long* replaced;  // [1] device counter: NaN / inf entries replaced (may be null)
+};
+
+// waic.py:112-135
+template <typename T>
+__device__ __forceinline__ T waic_sanitize(T x, unsigned& nrep) {
+  const bool nan = x != x;
+  const bool inf = !nan && (x - x != (T)0);  // +-inf
+  if (nan || inf) ++nrep;
+  if (nan) return (T)-1e10;
+  if (inf) return x > (T)0 ? (T)1e10 : (T)-1e10;
+  return x;
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void waic_wave_kernel(WaicParams P) {
+  __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];
+  __shared__ __attribute__((aligned(16))) double lt[2 * kLogTabN];
+  constexpr int EPT = kWaveSlots, NQ = EPT / VEC;
+  const int tid = threadIdx.x;
+  for (int j = tid; j < kTabN; j += kWave * kWavesPerBlock) exp_table_entry(tab, j);
+  for (int j = tid; j < kLogTabN; j += kWave * kWavesPerBlock) log_table_entry(lt, j);
+  __syncthreads();
+  const int lane = wave_lane();
+  const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int S = P.n_draws;
+  const double inv_S = recip_fast((double)S), log_S = log((double)S);
+  const T* base = reinterpret_cast<const T*>(P.in);
+  const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + wv, nw = (int64_t)gridDim.x * kWavesPerBlock;
+  T v[kWaveSlots];
+  if (w0 < P.n_obs) issue_row_loads<T, VEC>(v, base + w0 * P.stride_obs, S);
+  unsigned nrep = 0;
+  for (int64_t r = w0; r < P.n_obs; r += nw) {
+    const int64_t rn = r + nw;
+    const T* rp_next = rn < P.n_obs ? base + rn * P.stride_obs : nullptr;
+    // (read through readfirstlane inside the loop: otherwise the 31 per-vector masks of pad_tail are
+    // hoisted out of the row loop and spill)
+    const int nvec = __builtin_amdgcn_readfirstlane(P.n_draws) / VEC;
+    const int qfull = nvec / kWave, qrem = nvec - qfull * kWave;
+    const __amdgpu_buffer_rsrc_t rs_next = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(rp_next ? rp_next : base), 0, rp_next ? S * (int)sizeof(T) : 0, 0x00020000);
+    // Slots past the row become copies of the lane's first vector: max / sums need no per-slot predicate,
+    // and the exactly known contribution of the copies is subtracted afterwards.
+    pad_tail<T, VEC, NQ - 1, false>(v, qfull, qrem, (T)0);
+    const double ncopy = (double)((NQ - qfull) - (lane < qrem ? 1 : 0));  // copies of the first vector in this lane
+    double first[VEC];
+    double mx, sum;
+    const auto pass1 = [&]() {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) first[e] = (double)v[e];
+      mx = -pinf();
+      sum = 0.0;
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        mx = fmax(mx, (double)v[i]);
+        sum += (double)v[i];
+      }
+      double s0 = 0.0;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s0 += first[e];
+      sum = wave_all<R_SUM>(fma(-ncopy, s0, sum));
+    };
+    // ---- pass 1: max, sum.  A NaN or an infinity anywhere in the row makes the sum non-finite: only
+    // then are the replacements of waic.py:112-135 applied (and counted) and the pass repeated.
+    pass1();
+    if (!isfinite(sum)) {
+      // every slot holds a draw of the row (the tail slots: copies of the first vector, counted back out)
+      unsigned rep_all = 0, rep_first = 0;
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        unsigned rep = 0;
+        v[i] = waic_sanitize(v[i], rep);
+        rep_all += rep;
+        if (i < VEC) rep_first += rep;
+      }
+      nrep += rep_all - (unsigned)ncopy * rep_first;
+      pass1();
+    }
+    const double m = wave_all<R_MAX>(mx);
+    const double mean = sum * inv_S;
+    // ---- pass 2: sum exp(x - m) and sum (x - mean)^2; the next row streams in behind it ----------
+    double se = 0.0, sq = 0.0;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const double x = (double)v[i];
+      se += exp_tab(fmax(x - m, -700.0), tab);
+      const double d = x - mean;
+      sq = fma(d, d, sq);
+      if ((i % VEC) == VEC - 1) issue_row_vector<T, VEC>(v, rs_next, i / VEC);
+    }
+    {
+      double e0 = 0.0, q0 = 0.0;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        e0 += exp_tab(fmax(first[e] - m, -700.0), tab);
+        const double d = first[e] - mean;
+        q0 = fma(d, d, q0);
+      }
+      se = fma(-ncopy, e0, se);
+      sq = fma(-ncopy, q0, sq);
+    }
+    se = wave_all<R_SUM>(se);
+    const double var = wave_all<R_SUM>(sq) * inv_S;
+    const double lppd = (log_tab(se, lt) + m) - log_S;  // utils.py:352-357
+    if (lane == 0) {
+      if (P.lppd_i) P.lppd_i[r] = lppd;
+      if (P.var_i) P.var_i[r] = var;
+      if (P.waic_i) P.waic_i[r] = P.scale_value * (lppd - var);
+    }
+  }
+  if (P.replaced) {
+    const unsigned tot = (unsigned)wave_all<R_SUM>((double)nrep);
+    if (lane == 0 && tot) atomicAdd(P.replaced, (unsigned long long)tot);
+  }
+}
+
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void waic_rows_kernel(WaicParams P) {
+  __shared__ double red[16];
+  const int tid = threadIdx.x;
+  const int S = P.n_draws;
+  unsigned nrep = 0;
+  for (int64_t r = blockIdx.x; r < P.n_obs; r += gridDim.x) {
+    const T* rp = reinterpret_cast<const T*>(P.in) + r * P.stride_obs;
+    double mx = -pinf(), sum = 0.0;
+    for (int s = tid; s < S; s += BLOCK) {
+      const double x = (double)waic_sanitize(rp[(int64_t)s * P.stride_draw], nrep);
+      mx = fmax(mx, x);
+      sum += x;
+    }
+    const double m = block_reduce<OpMax, BLOCK>(mx, red);
+    const double mean = block_reduce<OpSum, BLOCK>(sum, red) / (double)S;
+    double se = 0.0, sq = 0.0;
+    unsigned dummy = 0;
+    for (int s = tid; s < S; s += BLOCK) {
+      const double x = (double)waic_sanitize(rp[(int64_t)s * P.stride_draw], dummy);
+      se += exp(x - m);
+      sq += (x - mean) * (x - mean);
+    }
+    se = block_reduce<OpSum, BLOCK>(se, red);
+    const double var = block_reduce<OpSum, BLOCK>(sq, red) / (double)S;
+    const double lppd = (log(se) + m) - log((double)S);
+    if (tid == 0) {
+      if (P.lppd_i) P.lppd_i[r] = lppd;
+      if (P.var_i) P.var_i[r] = var;
+      if (P.waic_i) P.waic_i[r] = P.scale_value * (lppd - var);
+    }
+  }
+  if (P.replaced) {
+    const double tot = block_reduce<OpSum, BLOCK>((double)nrep, red);
+    if (tid == 0 && tot > 0.0) atomicAdd(P.replaced, (unsigned long long)tot);
+  }
+}
+
+}  // namespace pla

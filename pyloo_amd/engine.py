@@ -137,6 +137,37 @@ class Engine:
                                                lw.ctypes.data_as(C.c_void_p), diag.ctypes.data_as(C.c_void_p)))
         return lw, diag
 
+    # ------------------------------------------------------------------ WAIC pass
+    def waic(self, ll, scale_value=1.0, pointwise=True, aggregate=True):
+        """(n_obs, n_draws) log-likelihood -> ``dict(lppd_i, var_i, waic_i, agg)`` (``pla_waic``; the
+        slots of ``agg`` are documented in include/pyloo_amd.h)."""
+        if _is_torch_tensor(ll):
+            import torch
+
+            t = ll
+            if t.dim() != 2 or not t.is_cuda:
+                raise ValueError("expected a 2-D CUDA tensor")
+            if t.dtype not in (torch.float64, torch.float32):
+                raise TypeError(f"unsupported dtype {t.dtype}")
+            n, s = t.shape
+            mk = lambda: torch.empty(n, dtype=torch.float64, device=t.device)  # noqa: E731
+            lppd_i, var_i, waic_i = (mk(), mk(), mk()) if (pointwise or aggregate) else (None, None, None)
+            agg = torch.zeros(AGG_COUNT, dtype=torch.float64, device=t.device) if aggregate else None
+            p = lambda x: None if x is None else C.c_void_p(x.data_ptr())  # noqa: E731
+            code = _capi.PLA_F64 if t.dtype == torch.float64 else _capi.PLA_F32
+            check(self._lib.pla_waic(self._h, C.c_void_p(t.data_ptr()), code, n, s, t.stride(0), t.stride(1),
+                                     float(scale_value), PLA_DEVICE, self._stream(), p(lppd_i), p(var_i), p(waic_i), p(agg)))
+            return {"lppd_i": lppd_i, "var_i": var_i, "waic_i": waic_i, "agg": agg}
+        a = self._as_2d_host(ll)
+        n, s = a.shape
+        so = a.strides[0] // a.itemsize if n > 1 else s
+        lppd_i, var_i, waic_i = (np.empty(n), np.empty(n), np.empty(n)) if pointwise else (None, None, None)
+        agg = np.zeros(AGG_COUNT) if aggregate else None
+        p = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)  # noqa: E731
+        check(self._lib.pla_waic(self._h, a.ctypes.data_as(C.c_void_p), dtype_code(a.dtype), n, s, so, 1,
+                                 float(scale_value), PLA_HOST, None, p(lppd_i), p(var_i), p(waic_i), p(agg)))
+        return {"lppd_i": lppd_i, "var_i": var_i, "waic_i": waic_i, "agg": agg}
+
     # ------------------------------------------------------------------ reductions
     def reduce_pointwise(self, diag, loo_i, lppd_i, good_k):
         if _is_torch_tensor(loo_i):

@@ -37,6 +37,20 @@ class OracleEngine:
         agg[6] = diag.min() if n else np.inf
         return {"diag": diag, "loo_i": loo_i, "lppd_i": lppd_i, "agg": agg}
 
+    def waic(self, ll, scale_value=1.0, pointwise=True, aggregate=True):
+        raw = np.asarray(ll, dtype=np.float64)
+        w = orc.waic_arrays(raw, scale_value)
+        n = raw.shape[0]
+        agg = np.zeros(AGG_COUNT)
+        agg[0] = n
+        agg[1] = w["waic_i"].sum()
+        agg[2] = np.sum((w["waic_i"] - w["waic_i"].mean()) ** 2) if n else 0.0
+        agg[3] = w["var_i"].sum()
+        agg[4] = np.sum(w["var_i"] > 0.4)
+        agg[6] = w["var_i"].min() if n else np.inf
+        agg[7] = np.sum(~np.isfinite(raw))
+        return {"lppd_i": w["lppd_i"], "var_i": w["var_i"], "waic_i": w["waic_i"], "agg": agg}
+
     def importance_weights(self, logw, tail_count=0, method="psis"):
         logw = np.asarray(logw)
         with np.errstate(all="ignore"):
