@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpyloo_amd.so")
 SOURCES = ["pla_kernels.hip", "pla_capi.hip"]
-HEADERS = ["pla_kernels.h", "pla_device.h", os.path.join("..", "..", "include", "pyloo_amd.h")]
+PUBLIC_HEADER = os.path.join(HERE, "..", "include", "pyloo_amd.h")
 ARCH = "gfx950"
 
 
@@ -31,7 +31,8 @@ def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    # every file under csrc/ (the kernels live in headers) + the public header
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [PUBLIC_HEADER]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 

@@ -1,0 +1,249 @@
+// Chunked wave-per-observation LOO kernel: rows longer than one register chunk (S > 4096) and/or tail
+// counts up to 512 (small reff, S = 20 000).  Same pipeline as pla_wave.h, still ONE read of the row:
+//
+//   * the row passes through the 64 register slots per lane in chunks of 4096 draws; the loads of the
+//     next chunk (or of the next row's first chunk) stream into the registers the sweep has consumed;
+//   * nothing in the sweep needs the row maximum any more: the exponentials are taken relative to a
+//     PROVISIONAL shift m' (the maximum of the first chunk) and the two sums are rescaled by
+//     e^(-+(m - m')) once the true maximum m is known (|x'| <= R < 690 keeps everything finite);
+//   * the candidate threshold comes from the first chunk alone (the draws are exchangeable, so its
+//     group maxima estimate the same quantile of the whole row); candidates are kept as the raw
+//     input values and turned into x = raw - m exactly as the reference computes it (one rounding)
+//     after the last chunk;
+//   * per chunk: pad fix-up, max / min, sweep; only the last chunk can have pads, and by then the
+//     running minimum is final, so the pad value (smallest x of the row) and its exactly known
+//     contribution are handled as in the one-chunk kernel.
+//
+// Everything after the sweep is wave_back() of pla_wave.h.  LDS capacities: CapsBig (2 waves per
+// workgroup, 4 per CU).  Shapes: unit draw stride, 16-byte aligned rows, every chunk >= 256 draws.
+#pragma once
+
+#include "pla_wave.h"
+
+namespace pla {
+
+constexpr int kChunkDraws = kWave * kWaveSlots;  // 4096
+
+template <typename T, int VEC, typename SM, typename TB>
+__device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const FastParams& F, SM& sm, const TB& tb,
+                                                    const int64_t r, T (&v)[kWaveSlots], const T* rp_next) {
+  constexpr int EPT = kWaveSlots;
+  constexpr int NQ = EPT / VEC;
+  constexpr int kCand = SM::Caps::kCand;
+  constexpr bool LW = false;
+  const int lane = wave_lane();
+  const int S = __builtin_amdgcn_readfirstlane(P.n_draws);
+  const int M = __builtin_amdgcn_readfirstlane(P.tail_count);
+  const int gsz = __builtin_amdgcn_readfirstlane(F.gsz);
+  const int kq = __builtin_amdgcn_readfirstlane(F.kq);
+  constexpr int dbgs = 0;
+  const int mestM = __builtin_amdgcn_readfirstlane(F.mest_M);
+  const double logS = uniform_d(F.log_S);
+  const double INF = pinf();
+  const int nch = (S + kChunkDraws - 1) / kChunkDraws;
+  const T* row = reinterpret_cast<const T*>(P.in) + r * P.stride_obs;
+
+  double magic = kMagic, c256 = kC256;
+  asm volatile("" : "+v"(magic));
+  asm volatile("" : "+s"(c256));
+  const auto key_of = [&](double xx) { return __double2loint(fma(xx, c256, magic)); };
+
+  // state carried across the chunks of the row
+  double m_run = -INF, mn_run = INF;  // running max / min of raw = -ll (wave-uniform)
+  double mp = 0.0;                    // provisional shift: max raw of chunk 0
+  double t1p = 0.0;                   // candidate threshold relative to mp
+  double s1 = 0.0, s2 = 0.0;          // per-lane sums of e^x', e^-x'  (x' = raw - mp)
+  bool slow = false;
+  const unsigned cand0 = lds_addr(sm.cand);
+  const unsigned dump8 = cand0 + (unsigned)(kCand + kWave + lane) * 8u;
+  const unsigned lim8 = cand0 + 8u * kCand;
+  unsigned next8 = cand0, base8 = cand0;
+  const char* tabc = reinterpret_cast<const char*>(tb.tab);
+
+  wave_sync();  // previous row is done with the LDS scratch
+  {
+    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int i = 0; i < kWaveBins / (4 * kWave); ++i) *reinterpret_cast<uint4*>(&sm.hist[4 * (lane + kWave * i)]) = z4;
+  }
+
+#pragma unroll 1
+  for (int ch = 0; ch < nch; ++ch) {
+    const int Sc = (S - ch * kChunkDraws < kChunkDraws) ? S - ch * kChunkDraws : kChunkDraws;  // draws in this chunk
+    const int nvec = Sc / VEC, qfull = nvec / kWave, qrem = nvec - qfull * kWave;
+    const bool last = (ch == nch - 1);
+    // ---- pad fix-up (copies of the lane's first vector), max / min of the chunk --------------------
+    pad_tail<T, VEC, NQ - 1, false>(v, qfull, qrem, (T)0);
+    double mx, mn, gs;
+    {
+      const T ninf = (T)(-INF);
+      T cur = ninf, vmx = ninf, snap = ninf;
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        cur = vmax_nc<true>(v[i], cur);   // max raw
+        vmx = vmax_nc<false>(v[i], vmx);  // max ll = -min raw
+        if ((i == 3 || i == 7 || i == 15 || i == 31) && i < EPT) {
+          if (gsz == i + 1) {
+            asm volatile("");
+            snap = cur;
+          }
+        }
+      }
+      mx = (double)cur;
+      mn = -(double)vmx;
+      gs = (double)snap;
+    }
+    const double mc = wave_all<R_MAX>(mx);
+    const double mnc = wave_all<R_MIN>(mn);
+    m_run = fmax(m_run, mc);
+    mn_run = fmin(mn_run, mnc);
+    if (ch == 0) {
+      // speculative threshold from the first chunk's group maxima (see pla_wave.h); shift = its maximum
+      mp = mc;
+      double lo = wave_all<R_MIN>(gs), hi = mc;
+#pragma unroll 1
+      for (int it = 0; it < 9; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        const int below = __popcll(__ballot(gs < mid));
+        if (below >= kq) hi = mid; else lo = mid;
+      }
+      t1p = hi - mp;
+      if (!(t1p < 0.0)) slow = true;
+    }
+    // a non-finite maximum (inf / NaN draws) or a range that may overflow the sums: general kernel.
+    // The chunk is still swept (clamped shift) so that the streaming of the following chunk goes on.
+    if (!(m_run - mn_run < kWaveMaxRange)) slow = true;
+    const double shift = slow ? m_run : mp;  // any finite-or-not value will do once the row is lost
+    // pads (last chunk only): the smallest raw value of the row, now final
+    const double xpad = mn_run - mp;
+    if (last) {
+      if (key_of(xpad) >= key_of(t1p)) slow = true;  // pads would be counted as candidates
+      pad_tail<T, VEC, NQ - 1, true>(v, qfull, qrem, (T)(-mn_run));
+    }
+    // ---- sweep of the chunk (pla_wave.h, section 2) -------------------------------------------------
+    double nl256 = -kLn2_256, c6 = 1.66666666666666666667e-01;
+    int c4096 = 4096, cm4096 = -4096;
+    asm volatile("" : "+s"(nl256), "+s"(c6), "+s"(c4096), "+s"(cm4096));
+    int four = 4;
+    asm volatile("" : "+v"(four));
+    // what streams in behind the sweep: the next chunk of this row, or the first chunk of the next row
+    const T* rp_stream = last ? rp_next : row + (int64_t)(ch + 1) * kChunkDraws;
+    int bytes_stream = 0;
+    if (rp_stream) {
+      const int left = last ? S : S - (ch + 1) * kChunkDraws;
+      bytes_stream = (left < kChunkDraws ? left : kChunkDraws) * (int)sizeof(T);
+    }
+    const __amdgpu_buffer_rsrc_t rs_next = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(rp_stream ? rp_stream : row), 0, bytes_stream, 0x00020000);
+    constexpr int kPF = 3;
+    double px[kPF], pt[kPF];
+    int4 ptt[kPF];
+#pragma unroll
+    for (int i = 0; i < EPT + kPF; ++i) {
+      if (i >= kPF) {  // stage B of draw i - kPF
+        const int sl = (i - kPF) % kPF;
+        const double x = px[sl], t = pt[sl];
+        const int k = __double2loint(t);
+        const double rr = fma(t - magic, nl256, x);
+        const double r2 = rr * rr;
+        const double E = fma(r2, 0.5, 1.0);
+        const double O = fma(c6, r2, 1.0);
+        s1 = fma(__hiloint2double(mad_i24(k, c4096, ptt[sl].y), ptt[sl].x), fma(rr, O, E), s1);
+        s2 = fma(__hiloint2double(mad_i24(k, cm4096, ptt[sl].w), ptt[sl].z), fma(-rr, O, E), s2);
+        if ((i & 3) == 3) asm volatile("" : "+v"(s1), "+v"(s2));
+      }
+      if (i < EPT) {  // stage A of draw i
+        const int sl = i % kPF;
+        const double x = (-(double)v[i]) - shift;
+        const double t = fma(x, c256, magic);
+        const int k = __double2loint(t);
+        px[sl] = x;
+        pt[sl] = t;
+        ptt[sl] = *reinterpret_cast<const int4*>(tabc + byte0_shl(k, four));
+        const bool cand = x >= t1p;
+        const unsigned long long cm = __ballot(cand);
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
+        unsigned pos8 = (rank << 3) + base8;
+        asm("" : "+v"(pos8));
+        lds_store(cand ? pos8 : dump8, (double)v[i]);  // the INPUT value: x = -value - m follows after the last chunk
+        {
+          const unsigned pc = (unsigned)__popcll(cm);
+          asm("s_lshl3_add_u32 %0, %1, %0" : "+s"(next8) : "s"(pc) : "scc");
+        }
+        base8 = next8 < lim8 ? next8 : lim8;
+        if ((i % VEC) == VEC - 1) issue_row_vector<T, VEC>(v, rs_next, i / VEC);
+      }
+    }
+    if (last) {  // remove the pads' contribution (same code path, so it cancels to rounding)
+      const double x = xpad;
+      const double t = fma(x, kC256, magic);
+      const int k = __double2loint(t);
+      const double rr = fma(t - magic, -kLn2_256, x);
+      const int4 tt = *reinterpret_cast<const int4*>(tabc + 16 * (k & 255));
+      const double r2 = rr * rr;
+      const double E = fma(r2, 0.5, 1.0);
+      const double O = fma(1.66666666666666666667e-01, r2, 1.0);
+      const double npad = (double)((NQ - qfull) * VEC - ((lane < qrem) ? VEC : 0));
+      s1 = fma(-npad * __hiloint2double(tt.y + (k << 12), tt.x), fma(rr, O, E), s1);
+      s2 = fma(-npad * __hiloint2double(tt.w - (k << 12), tt.z), fma(-rr, O, E), s2);
+    }
+  }
+
+  // ---- the row maximum is known: candidates -> x, sums -> true shift ---------------------------------
+  const double m = m_run, mn = mn_run, R = m - mn;
+  const double delta = m - mp;  // >= 0
+  const unsigned ncand = (next8 - cand0) >> 3;
+  double khat = INF, loo = 0.0, lppd = 0.0;
+  wave_sync();
+  if (!slow && ((int)ncand < M + 1 || ncand > (unsigned)kCand)) slow = true;
+  if (!slow) {
+    for (unsigned c = lane; c < ncand; c += kWave) sm.cand[c] = (-sm.cand[c]) - m;  // psis.py:134, one rounding
+    s1 *= exp_tab(-delta, tb.tab);  // e^x = e^x' e^-(m - m');  s2 is rescaled in log space (lppd_shift)
+    // histogram origin one key below the threshold: x and the threshold were rounded on different paths
+    const int k1 = key_of(t1p - delta) - 1;
+    const int span = -k1;
+    const int sh = (span >> 9) ? (32 - __builtin_clz((unsigned)(span >> 9))) : 0;
+    const int nvl = (S - (nch - 1) * kChunkDraws) / VEC;  // qfull / qrem of the last chunk (unused by LOO mode)
+    wave_sync();
+    wave_back<T, VEC, LW, SM, TB>(P, sm, tb, r, v, lane, S, M, mestM, logS, dbgs, m, mn, R, delta, s1, s2, ncand, k1, sh,
+                                  magic, c256, nvl / kWave, nvl % kWave, slow, khat, loo, lppd);
+  }
+  if (lane == 0) {
+    if (slow) {
+      const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
+      F.slow_list[idx] = (unsigned)r;
+    } else {
+      if (P.diag) P.diag[r] = khat;
+      if (P.loo_i) P.loo_i[r] = P.scale_value * loo;
+      if (P.lppd_i) P.lppd_i[r] = lppd;
+    }
+  }
+}
+
+template <typename T, int VEC, class CAP>
+__global__ __launch_bounds__(kWave * CAP::kWaves, 1) void wave_loo_chunked_kernel(RowsParams P, FastParams F) {
+  using SM = WaveSmemT<CAP>;
+  using TB = WaveTablesT<CAP>;
+  constexpr int kWavesPerBlock = CAP::kWaves;
+  __shared__ __attribute__((aligned(16))) SM scratch[kWavesPerBlock];
+  __shared__ __attribute__((aligned(16))) TB tb;
+  const int tid = threadIdx.x;
+  for (int j = tid; j < kTabN; j += kWave * kWavesPerBlock) exp_table_entry(tb.tab, j);
+  for (int j = tid; j < kLogTabN; j += kWave * kWavesPerBlock) log_table_entry(tb.lt, j);
+  for (int j = tid; j < P.tail_count; j += kWave * kWavesPerBlock) tb.l1[j] = F.l1_table[j];
+  if (tid < kWave) tb.bg[tid] = F.b_grid[tid];
+  __syncthreads();
+  const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+  SM& sm = scratch[wv];
+  T v[kWaveSlots];
+  const T* base = reinterpret_cast<const T*>(P.in);
+  const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + wv, nw = (int64_t)gridDim.x * kWavesPerBlock;
+  const int first = P.n_draws < kChunkDraws ? P.n_draws : kChunkDraws;
+  if (w0 < P.n_obs) issue_row_loads<T, VEC>(v, base + w0 * P.stride_obs, first);
+  for (int64_t r = w0; r < P.n_obs; r += nw) {
+    const int64_t rn = r + nw;
+    wave_loo_row_chunked<T, VEC, SM, TB>(P, F, sm, tb, r, v, rn < P.n_obs ? base + rn * P.stride_obs : nullptr);
+  }
+}
+
+}  // namespace pla

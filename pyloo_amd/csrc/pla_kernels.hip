@@ -19,6 +19,7 @@
 #include "pla_rows.h"
 #include "pla_wave.h"
 #include "pla_waic.h"
+#include "pla_chunked.h"
 
 namespace pla {
 
@@ -192,11 +193,13 @@ static hipError_t launch_one(const RowsParams& p, hipStream_t stream) {
 // over the first gsz register slots.  For exchangeable draws a draw lies below it with probability F,
 // F^gsz = kq/64.  Pick (gsz, kq) so that ~2.6(M+1) draws lie above, with kq large enough for the order
 // statistic to be stable.  Returns false when no setting fits (the general kernel takes the call).
-static bool wave_threshold_params(int S, int vec, int M, int* gsz_out, int* kq_out) {
+// `cand_cap`: capacity of the LDS candidate list; only the first min(S, 4096) draws feed the maxima.
+static bool wave_threshold_params(int S, int vec, int M, int* gsz_out, int* kq_out, int cand_cap = kCandCap) {
   const double target = 2.6 * (M + 1);
-  if (target > 0.62 * kCandCap || target >= 0.5 * S) return false;
+  if (target > 0.62 * cand_cap || target >= 0.5 * S) return false;
   const double F = 1.0 - target / S;
-  const int valid = (S / vec / kWave) * vec;  // slots that are real draws in every lane
+  const int S0 = S < kWave * kWaveSlots ? S : kWave * kWaveSlots;
+  const int valid = (S0 / vec / kWave) * vec;  // slots that are real draws in every lane
   int best_g = 0, best_k = 0;
   for (int g = 4; g <= 32; g <<= 1) {
     if (g > valid) break;
@@ -228,13 +231,35 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, hipStream_t 
   // 256 CUs (8 waves each) busy with a short tail
   int64_t grid = (p.n_obs + kWavesPerBlock - 1) / kWavesPerBlock;
   if (grid > 2048 * 8 / kWavesPerBlock) grid = 2048 * 8 / kWavesPerBlock;
-  hipLaunchKernelGGL((wave_loo_kernel<T, VEC, LW>), dim3((unsigned)grid), dim3(kWave * kWavesPerBlock), 0, stream, p, f);
+  hipLaunchKernelGGL((wave_loo_kernel<T, VEC, LW, CapsSmall>), dim3((unsigned)grid), dim3(kWave * kWavesPerBlock), 0, stream, p, f);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   // general kernel over whatever the fast path declined (usually nothing)
   constexpr int BLOCK = 256;
   int64_t g2 = p.n_obs < 1024 ? p.n_obs : 1024;
   hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK, LW>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap),
+                     stream, p);
+  return hipGetLastError();
+}
+
+// long rows (chunks of 4096 draws) and / or tail counts up to 512: pla_chunked.h
+template <typename T, int VEC>
+static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return e;
+  int root_ = (int)std::sqrt((double)p.tail_count);
+  while (root_ * root_ > p.tail_count) --root_;
+  while ((root_ + 1) * (root_ + 1) <= p.tail_count) ++root_;
+  FastParams f{gsz, kq, p.slow_list, p.counters, 0, p.l1_table, std::log((double)p.n_draws), p.l1_table + p.tail_count, 30 + root_};
+  constexpr int W = CapsBig::kWaves;  // 2 waves per workgroup, 2 workgroups per CU (LDS)
+  int64_t grid = (p.n_obs + W - 1) / W;
+  if (grid > 256 * 2 * 8) grid = 256 * 2 * 8;
+  hipLaunchKernelGGL((wave_loo_chunked_kernel<T, VEC, CapsBig>), dim3((unsigned)grid), dim3(kWave * W), 0, stream, p, f);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  constexpr int BLOCK = 256;
+  int64_t g2 = p.n_obs < 1024 ? p.n_obs : 1024;
+  hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK, false>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap),
                      stream, p);
   return hipGetLastError();
 }
@@ -254,6 +279,18 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream) {
       int gsz = 0, kq = 0;
       if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq)) {
         return launch_wave<T, WVEC, LW>(p, gsz, kq, stream);
+      }
+    }
+    if constexpr (!LW) {
+      // rows beyond one register chunk or tails beyond the small kernel's LDS: the chunked kernel
+      const int last_chunk = p.n_draws - ((p.n_draws - 1) / kChunkDraws) * kChunkDraws;
+      if (path != 1 && unit && waligned && p.method == PLA_PSIS && p.slow_list && p.counters && p.l1_table &&
+          p.n_draws >= 256 && p.n_draws <= (1 << 20) && last_chunk >= kWave * WVEC && p.tail_count <= CapsBig::kMaxTail &&
+          smem_bytes(BLOCK, p.tail_cap) <= 64 * 1024 && p.n_obs <= 0xffffffffll) {
+        int gsz = 0, kq = 0;
+        if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, CapsBig::kCand)) {
+          return launch_chunked<T, WVEC>(p, gsz, kq, stream);
+        }
       }
     }
     if (path == 1) return launch_one<T, BLOCK, 0, LW>(p, stream);

@@ -51,9 +51,22 @@ namespace pla {
 #endif
 constexpr int kWaveSlots = PLA_WAVE_SLOTS;   // register slots per lane -> S <= 4096
 constexpr int kWaveBins = 512;   // histogram bins over the candidate list
-constexpr int kCandCap = PLA_CAND_CAP;    // candidates (draws above the speculative threshold) kept in LDS
-constexpr int kWaveCap = 320;    // candidates kept in LDS; needs M + boundary-bin extras
-constexpr int kWaveMaxTail = 250;
+// LDS capacities of one wave's scratch, as a trait so that the kernel exists in two sizes
+struct CapsSmall {                                  // S <= 4096, M <= 250: 8 waves per CU
+  static constexpr int kCand = PLA_CAND_CAP;        // candidates (draws above the speculative threshold) kept in LDS
+  static constexpr int kSa = 320;                   // candidates at/above the boundary bin: M + boundary-bin extras
+  static constexpr int kMaxTail = 250;              // largest tail count M
+  static constexpr int kWaves = PLA_WAVES_PER_BLOCK;  // independent waves per workgroup (they only share the tables)
+};
+struct CapsBig {                                    // long rows in chunks / small reff: M <= 512, 4 waves per CU
+  static constexpr int kCand = 2048;
+  static constexpr int kSa = 768;
+  static constexpr int kMaxTail = 512;
+  static constexpr int kWaves = 2;
+};
+constexpr int kCandCap = CapsSmall::kCand;
+constexpr int kWaveCap = CapsSmall::kSa;
+constexpr int kWaveMaxTail = CapsSmall::kMaxTail;
 constexpr double kWaveMaxRange = 690.0;  // nats: e^x, e^-x and their sums over 4096 draws stay finite and normal
 
 // ---- wave-wide reductions with DPP (result in SGPRs) -----------------------------------------
@@ -138,28 +151,35 @@ __device__ __forceinline__ double wave_all(double v) {
   return lane_value(v, 63);
 }
 
-struct WaveSmem {
+template <class CAP>
+struct WaveSmemT {
+  using Caps = CAP;
   unsigned hist[kWaveBins];
   unsigned short start[kWaveBins];  // #candidates in bins above b
-  double cand[kCandCap + 2 * kWave];  // candidate x values (+ 64 overflow slots + one dump slot per lane); reused for the
+  double cand[CAP::kCand + 2 * kWave];  // candidate x values (+ 64 overflow slots + one dump slot per lane); reused for the
                                     // candidates sorted descending once they are binned
-  double sa[kWaveCap + 4];          // candidates at/above the boundary bin, grouped by bin (+ 4 sentinels); later y ascending
+  double sa[CAP::kSa + 4];          // candidates at/above the boundary bin, grouped by bin (+ 4 sentinels); later y ascending
 };
 // weights mode (psislw): the candidates carry their draw index so that the smoothed tail can be
 // written back to its positions
-struct WaveSmemLW : WaveSmem {
-  unsigned short ids[kCandCap + 2 * kWave];  // draw index of cand[c]
-  unsigned short sa_id[kWaveCap + 4];        // ... of sa[c]
-  unsigned short sb_id[kWaveCap];            // ... of the sorted candidates
+template <class CAP>
+struct WaveSmemLWT : WaveSmemT<CAP> {
+  unsigned short ids[CAP::kCand + 2 * kWave];  // draw index of cand[c]
+  unsigned short sa_id[CAP::kSa + 4];          // ... of sa[c]
+  unsigned short sb_id[CAP::kSa];              // ... of the sorted candidates
 };
+using WaveSmem = WaveSmemT<CapsSmall>;
+using WaveSmemLW = WaveSmemLWT<CapsSmall>;
 // read-only tables shared by the waves of a workgroup
-struct WaveTables {
+template <class CAP>
+struct WaveTablesT {
   double tab[2 * kTabN];            // biased {2^(j/256), 2^(-j/256)} pairs (pla_math.h): one 16-byte read serves both exponentials
   double lt[2 * kLogTabN];          // {1/c_j, log c_j} for log_tab (pla_math.h)
-  double l1[kWaveMaxTail + 6];      // log1p(-(j+0.5)/M), j < M  (host libm, psis.py:153,219-221)
+  double l1[CAP::kMaxTail + 6];      // log1p(-(j+0.5)/M), j < M  (host libm, psis.py:153,219-221)
   double bg[kWave];                 // 1 - sqrt(m_est/(j+0.5)) for m_est(M)  (psis.py:186)
 };
-constexpr int kWavesPerBlock = PLA_WAVES_PER_BLOCK;   // independent waves per workgroup (they only share the tables)
+using WaveTables = WaveTablesT<CapsSmall>;
+constexpr int kWavesPerBlock = CapsSmall::kWaves;
 __device__ __forceinline__ int wave_lane() { return (int)threadIdx.x & (kWave - 1); }
 
 // phase ablation for profiling (tools/ablate.sh); compiled out of the production kernel
@@ -250,14 +270,418 @@ __device__ __forceinline__ void pad_tail(T (&v)[kWaveSlots], int qfull, int qrem
   }
 }
 
+// Everything after the sweep: exact selection of the M+1 largest among the candidates, GPD fit,
+// smoothing sums and the outputs.  Shared by the one-chunk and the chunked front ends; `lppd_shift` is
+// the log of the factor by which the chunked front's s2 is short (0 otherwise).
+template <typename T, int VEC, bool LW, typename SM, typename TB>
+__device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB& tb, const int64_t r, T (&v)[kWaveSlots],
+                                          const int lane, const int S, const int M, const int mestM, const double logS,
+                                          const int dbgs, const double m, const double mn, const double R,
+                                          const double lppd_shift, double s1, double s2, const unsigned ncand,
+                                          const int k1, const int sh, const double magic, const double c256,
+                                          const int qfull, const int qrem, bool& slow, double& khat, double& loo,
+                                          double& lppd) {
+  constexpr int NQ = kWaveSlots / VEC;
+  constexpr int kSa = SM::Caps::kSa;
+  const double INF = pinf();
+  const double* l1tab = tb.l1;
+  const double* bgrid = tb.bg;
+  const auto key_of = [&](double xx) { return __double2loint(fma(xx, c256, magic)); };
+  (void)NQ;
+  // ---- 3. histogram of the candidate list, suffix scan (8 bins per lane) ---------------------
+  PLA_PHASE(4);
+  unsigned one = 1u;
+  asm volatile("" : "+v"(one));
+  // four list entries per lane and trip: the LDS reads go out together instead of one round trip each
+  for (unsigned c0 = lane; c0 < ncand; c0 += 4 * kWave) {
+    double xs[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned c = c0 + u * kWave;
+      xs[u] = sm.cand[c < ncand ? c : c0];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned c = c0 + u * kWave;
+      atomicAdd(&sm.hist[(key_of(xs[u]) - k1) >> sh], c < ncand ? one : 0u);  // past the end: add 0
+    }
+  }
+  wave_sync();
+  PLA_PHASE(5);
+  int bstar = 0, C1 = 0;
+  {
+    unsigned c[8];
+    unsigned tot = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint4 h = *reinterpret_cast<const uint4*>(&sm.hist[8 * lane + 4 * i]);
+      c[4 * i] = h.x; c[4 * i + 1] = h.y; c[4 * i + 2] = h.z; c[4 * i + 3] = h.w;
+      tot += h.x + h.y + h.z + h.w;
+    }
+    // inclusive prefix sum over the 64 lanes with DPP adds (no LDS round trips), then suffix = total - prefix
+    unsigned pre = tot;
+    pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)tot, 0x111, 0xF, 0xF, true);   // row_shr:1
+    pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)tot, 0x112, 0xF, 0xF, true);   // row_shr:2
+    pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)tot, 0x113, 0xF, 0xF, true);   // row_shr:3
+    pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x114, 0xF, 0xE, false);  // row_shr:4, banks 1-3
+    pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x118, 0xF, 0xC, false);  // row_shr:8, banks 2-3
+    pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x142, 0xA, 0xF, false);  // row_bcast:15
+    pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x143, 0xC, 0xF, false);  // row_bcast:31
+    const unsigned all = (unsigned)__builtin_amdgcn_readlane((int)pre, kWave - 1);
+    const unsigned suf = all - pre + tot;  // this lane's bins and everything above
+    unsigned a = suf - tot;  // candidates in bins owned by higher lanes
+    int fb = -1, fc = 0;
+    unsigned st[8];
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+      st[i] = a;
+      if ((unsigned)M >= a && (unsigned)M < a + c[i]) {
+        fb = 8 * lane + i;
+        fc = (int)(a + c[i]);
+      }
+      a += c[i];
+    }
+    *reinterpret_cast<uint4*>(&sm.start[8 * lane]) =
+        make_uint4(st[0] | (st[1] << 16), st[2] | (st[3] << 16), st[4] | (st[5] << 16), st[6] | (st[7] << 16));
+    const unsigned long long who = __ballot(fb >= 0);
+    const int src = __ffsll((long long)who) - 1;
+    bstar = __builtin_amdgcn_readlane(fb, src);
+    C1 = __builtin_amdgcn_readlane(fc, src);
+  }
+  wave_sync();
+  if (C1 > kSa) {
+    slow = true;
+  } else {
+    // ---- 4. candidates at/above the boundary bin -> sa, grouped by bin (descending bins) --------
+    PLA_PHASE(6);
+    const int kstar = k1 + (bstar << sh);
+    for (unsigned c0 = lane; c0 < ncand; c0 += 4 * kWave) {
+      double xs[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned c = c0 + u * kWave;
+        xs[u] = sm.cand[c < ncand ? c : c0];
+      }
+      unsigned short idv[4] = {0, 0, 0, 0};
+      if constexpr (LW) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned c = c0 + u * kWave;
+          idv[u] = sm.ids[c < ncand ? c : c0];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned c = c0 + u * kWave;
+        const double x = xs[u];
+        const int k = key_of(x);
+        if (c < ncand && k >= kstar) {
+          const int b = (k - k1) >> sh;
+          const unsigned slot = sm.start[b] + (atomicSub(&sm.hist[b], 1u) - 1u);
+          sm.sa[slot] = x;
+          if constexpr (LW) sm.sa_id[slot] = idv[u];
+        }
+      }
+    }
+    if (lane < 4) sm.sa[C1 + lane] = -INF;  // sentinels for the 4-wide reads of the ranking loop
+    wave_sync();
+    PLA_PHASE(7);
+    double* sb = sm.cand;  // the list is consumed: its storage now holds the sorted candidates
+    // ---- 5. exact descending rank inside each bin (ties: arbitrary, the sums do not care) --
+    for (int c = lane; c < C1; c += kWave) {
+      const double x = sm.sa[c];
+      const int b = (key_of(x) - k1) >> sh;
+      const int lo = (int)sm.start[b];
+      const int hi = (b > 0) ? (int)sm.start[b - 1] : C1;
+      int cnt = 0, same = 0;
+      // four neighbours per trip (one LDS round trip): entries past the bin are smaller values of
+      // lower bins, entries past the end are -inf sentinels, so neither counts
+      for (int c2 = lo; c2 < hi; c2 += 4) {
+        double x2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x2[u] = sm.sa[c2 + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          cnt += (x2[u] > x) ? 1 : 0;
+          same += (x2[u] == x) ? 1 : 0;  // counts the element itself
+        }
+      }
+      if (__ballot(same > 1) != 0ull) {  // duplicates (repeated draws): order them by position
+        if (same > 1)
+          for (int c2 = lo; c2 < c; ++c2) cnt += (sm.sa[c2] == x) ? 1 : 0;
+      }
+      sb[lo + cnt] = x;
+      if constexpr (LW) sm.sb_id[lo + cnt] = sm.sa_id[c];
+    }
+    wave_sync();
+    // ---- cutoff (psis.py:135-141); R < 690: the log(DBL_MIN) floor cannot bind -------------
+    PLA_PHASE(8);
+    const double xcut = sb[M];
+    int n = M;
+    while (n > 0 && sb[n - 1] == xcut) --n;  // ties at the cutoff leave the tail
+    const double e_cut = exp_tab(xcut, tb.tab);
+    double acc_t = 0.0, acc_r = 0.0;  // (sum w' - sum e) and sum w'/e over the tail
+    bool smoothed = false;
+    if (n > 4 && !(dbgs & 8)) {
+      wave_sync();
+      // y ascending (psis.py:146-147), stored with the pair sums / products the fit loop eats
+      // (the reciprocals e^-x of the same range reduction are kept for the weight ratios below)
+      double* inv_e = sb + kSa + kWave;  // beyond the sorted candidates and the pair data
+      const int n32 = (n + 31) & ~31;  // padded with y = 0 (factor 1) so that the fit runs whole trips only
+      // Straight-line code for 3 (n <= 192, the usual case) or 4 elements per lane: the independent
+      // exp chains interleave instead of running one LDS round trip + ~20 dependent fp64 ops at a time.
+      // Every slot up to 64 U is written (zeros past n), so the later loops need no bounds either.
+      const bool three = n32 <= 3 * kWave;
+      const auto y_pass = [&](auto UC) {
+        constexpr int U = decltype(UC)::value;
+        double xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = lane + kWave * u;
+          xv[u] = sb[j < n ? n - 1 - j : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = lane + kWave * u;
+          double ep, en;
+          exp_pair(xv[u], tb.tab, ep, en);
+          sm.sa[j] = j < n ? ep - e_cut : 0.0;
+          inv_e[j] = en;
+        }
+      };
+      constexpr bool kBigTail = SM::Caps::kMaxTail > 4 * kWave;  // tails of up to 8 elements per lane
+      const bool eight = kBigTail && n32 > 4 * kWave;
+      if (three) y_pass(std::integral_constant<int, 3>{});
+      else if (!eight) y_pass(std::integral_constant<int, 4>{});
+      else if constexpr (kBigTail) y_pass(std::integral_constant<int, 8>{});
+      wave_sync();
+      const double* y = sm.sa;
+      const double nn = (double)n;
+      // (1 - b y0)(1 - b y1) = 1 - b (y0 + y1) + b^2 y0 y1: pair sums / products once per row
+      {
+        constexpr int PU = kBigTail ? 4 : 2;  // pairs per lane
+        double2 yy[PU];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) yy[u] = *reinterpret_cast<const double2*>(y + 2 * (lane + kWave * u));
+#pragma unroll
+        for (int u = 0; u < PU; ++u)
+          *reinterpret_cast<double2*>(&sb[2 * (lane + kWave * u)]) = make_double2(yy[u].x + yy[u].y, yy[u].x * yy[u].y);
+      }
+      wave_sync();
+      const double* yp = sb;
+      // ---- 6. GPD fit (psis.py:163-208), lane j <-> grid point b_j -------------------------
+      PLA_PHASE(9);
+      const int mest = 30 + isqrt_i(n);
+      const double yq = y[((n + 2) >> 2) - 1];
+      const double yn = y[n - 1];
+      const bool act = lane < mest;
+      // psis.py:186: 1 - sqrt(m_est / (j - 0.5)); host table for the usual n == M
+      double b = (mest == mestM) ? bgrid[lane] : 1.0 - sqrt((double)mest / ((double)(lane + 1) - 0.5));
+      b = div_fast(b, 3.0 * yq);   // psis.py:187
+      b += recip_fast(yn);         // psis.py:188
+      const double b_first = lane_value(b, 0);  // most negative grid point
+      const double b_last = lane_value(b, mest - 1);
+      const double fbig = fma(-b_first, yn, 1.0), fsmall = fma(-b_last, yn, 1.0);
+      const bool wide = (fbig < 0x1p30) && (fsmall > 0x1p-30);  // 16 factors per accumulator between renorms
+      // lanes whose b_j is ~0 would lose the low bits of b_j*y in 1 - b_j*y: carry them along
+      const bool tiny = __ballot(act && fabs(b * yn) < 0.015625) != 0ull;
+      PLA_PHASE(10);
+      ProdAcc acc, acc2;
+      acc.init();
+      acc2.init();
+      const double nb = -b;
+      double corr = 0.0;
+      int i = 0;
+      if (wide && !tiny) {
+        // factors within 2^+-15: four trips (8 pair factors per accumulator each) fit between renorms
+        const bool narrow = (fbig < 0x1p15) && (fsmall > 0x1p-15);
+        for (; i < n32; i += 32) {
+#pragma unroll
+          for (int u = 0; u < 32; u += 4) {
+            const double2 pa = *reinterpret_cast<const double2*>(yp + i + u);
+            const double2 pb = *reinterpret_cast<const double2*>(yp + i + u + 2);
+            acc.mul(fma(nb, fma(nb, pa.y, pa.x), 1.0));
+            acc2.mul(fma(nb, fma(nb, pb.y, pb.x), 1.0));
+          }
+          if (!narrow || (i & 96) == 96) {
+            acc.renorm();
+            acc2.renorm();
+          }
+        }
+        acc.renorm();
+        acc2.renorm();
+      } else {
+        for (; i < n; ++i) {
+          const double yi = y[i];
+          const double f = fma(nb, yi, 1.0);
+          corr += fma(nb, yi, 1.0 - f) * __builtin_amdgcn_rcp(f);  // rounding error of f, relative
+          acc.mul(f);
+          acc.renorm();
+        }
+      }
+      PLA_PHASE(11);
+      acc.m *= acc2.m;
+      acc.e += acc2.e;
+      const double rn = recip_fast(nn);
+      const double kj = ((log_tab(acc.m, tb.lt) + (double)acc.e * kLn2) + corr) * rn;   // psis.py:190
+      const double ls = nn * (log_tab(act ? -div_fast(b, kj) : 1.0, tb.lt) - kj - 1.0);             // psis.py:191
+      const double lmax = wave_all<R_MAX>(act ? ls : -INF);
+      // NaN anywhere, or max = +-inf: every weight is NaN in the reference -> nothing is kept
+      const bool anynan = (__ballot(act && (ls != ls)) != 0ull) || !(fabs(lmax) < INF);
+      double w = act ? exp_neg(ls - lmax, tb.tab) : 0.0;                          // psis.py:192
+      const double se = wave_all<R_SUM>(w);
+      w = anynan ? qnan() : w * recip_fast(se);
+      const bool keep = act && (w >= 10.0 * kEps);                                // psis.py:194-197
+      const double sw = wave_all<R_SUM>(keep ? w : 0.0);
+      const double bw = wave_all<R_SUM>(keep ? b * w : 0.0);
+      const double b_post = (sw > 0.0) ? div_fast(bw, sw) : 0.0;                  // psis.py:198,201
+      // psis.py:203: mean_i log1p(-b_post*y_i) as the log of per-lane products
+      PLA_PHASE(12);
+      double pr;
+      {  // y is zero past n: no bounds
+        const double f0 = fma(-b_post, y[lane], 1.0), f1 = fma(-b_post, y[lane + kWave], 1.0);
+        const double f2 = fma(-b_post, y[lane + 2 * kWave], 1.0);
+        pr = f0 * f1 * f2;
+        if (!three) pr *= fma(-b_post, y[lane + 3 * kWave], 1.0);
+        if constexpr (kBigTail) {
+          if (eight) {
+            double pr2 = 1.0;
+#pragma unroll
+            for (int u = 4; u < 8; ++u) pr2 *= fma(-b_post, y[lane + u * kWave], 1.0);
+            pr *= pr2;
+          }
+        }
+      }
+      const double k_post = wave_all<R_SUM>(log_tab(pr, tb.lt)) * rn;
+      const double sigma = -k_post / b_post;                                      // psis.py:205
+      khat = (nn * k_post + 5.0) / (nn + 10.0);                                   // psis.py:206
+      PLA_PHASE(13);
+      if (isfinite(khat)) {
+        const double* inv_e = sb + kSa + kWave;
+        double* wtail = sb + kSa + kWave;  // weights mode: overwrites inv_e (not needed there)
+        smoothed = true;
+        const double rk = 1.0 / khat;
+        const bool ktiny = fabs(khat) < kEps;
+        if (sigma > 0.0 && !ktiny && n == M) {
+          // the usual case, straight-line: w_j = sigma/k (e^{z_j} - 1) + e_cut with z_j = -k log1p(-p_j) from
+          // the host table (psis.py:153,218-221).  e^z - 1 by subtraction is accurate to 1e-16 ABSOLUTE,
+          // which is all the sum w_j + e_cut can see.
+          const double coef = sigma * rk, off = e_cut - coef;
+          const auto smooth_pass = [&](auto UC) {
+            constexpr int U = decltype(UC)::value;
+            double ez[U], yv[U], iv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const int j = lane + kWave * u;
+              const double z = fmin(-khat * l1tab[j < n ? j : 0], 700.0);
+              ez[u] = exp_tab(z, tb.tab);
+              yv[u] = y[j];
+              iv[u] = inv_e[j];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const int j = lane + kWave * u;
+              double wj = fma(ez[u], coef, off);  // exp(log(q + e_cut)), psis.py:155
+              wj = fmin(wj, 1.0);                 // psis.py:157
+              const double ej = yv[u] + e_cut;
+              acc_t += (j < n) ? wj - ej : 0.0;
+              acc_r += (j < n) ? wj * iv[u] : 0.0;
+              if constexpr (LW) wtail[j] = wj;  // (clipped) smoothed weight of tail element j
+            }
+          };
+          if (three) smooth_pass(std::integral_constant<int, 3>{});
+          else if (!eight) smooth_pass(std::integral_constant<int, 4>{});
+          else if constexpr (kBigTail) smooth_pass(std::integral_constant<int, 8>{});
+        } else {
+          for (int j = lane; j < n; j += kWave) {
+            // log1p(-p_j), p_j = (j + 0.5)/n (psis.py:153): host table when n == M
+            const double l1 = (n == M) ? l1tab[j] : log_fast(1.0 - ((double)j + 0.5) * rn);
+            double q;
+            if (sigma <= 0.0) {
+              q = qnan();                                                           // psis.py:214-215
+            } else {
+              q = ktiny ? -l1 : expm1_tab(-khat * l1, tb.tab) * rk;                 // psis.py:218-221
+              q *= sigma;
+            }
+            double wj = q + e_cut;   // exp(log(q + e_cut)), psis.py:155
+            if (wj > 1.0) wj = 1.0;  // psis.py:157
+            const double ej = y[j] + e_cut;
+            acc_t += wj - ej;
+            acc_r = fma(wj, inv_e[j], acc_r);
+            if constexpr (LW) wtail[j] = wj;
+          }
+        }
+      }
+    }
+    // total = sum_nontail e^x + sum_tail w' = (s1 - sum_tail e) + sum_tail w'
+    PLA_PHASE(14);
+    // The tail's exponentials are subtracted from a sum that contains them (acc_t = sum w' - sum e): when
+    // the smoothed tail is far lighter than the raw one (a draw tens of nats above the rest) that
+    // cancels catastrophically, and such rows are left to the general kernel, which sums like the reference.
+    const double s1_all = wave_all<R_SUM>(s1);
+    const double total = smoothed ? s1_all + wave_all<R_SUM>(acc_t) : s1_all;
+    if (!(total > 0.01 * s1_all)) slow = true;
+    if constexpr (LW) {
+      // ---- weights mode: lw_s = x_s - log(total) for every draw, the smoothed tail at its positions ----
+      const double L = log_tab(total, tb.lt);  // psis.py:158 (_logsumexp of the shifted, smoothed row)
+      if (!(total > 1e-280) || !isfinite(L)) {
+        slow = true;
+      } else {
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        T* orow = reinterpret_cast<T*>(P.lw_out) + r * (int64_t)S;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(orow, 0, S * (int)sizeof(T), 0x00020000);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          if (q <= qfull) {  // later vectors lie past the row (stores past the end are dropped anyway)
+            v4i t;
+            if constexpr (VEC == 2) {
+              const double a0 = ((double)v[2 * q] - m) - L, a1 = ((double)v[2 * q + 1] - m) - L;
+              t[0] = __double2loint(a0); t[1] = __double2hiint(a0);
+              t[2] = __double2loint(a1); t[3] = __double2hiint(a1);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) t[e] = __float_as_int((float)(((double)v[4 * q + e] - m) - L));
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(t, ro, lane * 16, q * (kWave * 16), 0);
+            // gfx9 hazard: a VALU write to the data registers of a > 8-byte buffer store with an SGPR offset
+            // needs a wait state after the store.  The compiler's hazard pass misses it across the block
+            // boundary that follows the last store (observed: the low dword of the stored value replaced
+            // by the next instruction's literal), so the registers are kept alive over one s_nop.
+            asm volatile("s_nop 0" : : "v"(t));
+          }
+        }
+        if (smoothed) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the patches below must land after the row
+          const double* wtail = sb + kSa + kWave;
+          for (int j = lane; j < n; j += kWave) {
+            const int id = (int)sm.sb_id[n - 1 - j];
+            orow[id] = (T)(log_tab(wtail[j], tb.lt) - L);  // psis.py:155-158
+          }
+        }
+      }
+    } else {
+      s2 = wave_all<R_SUM>(s2);
+      // loo_i = -m - L + log(tail_ratio),  L = log(total) (psis.py:158; loo.py:289,319-324): one log
+      double tail_ratio = (double)S;
+      if (smoothed) tail_ratio = (double)(S - n) + wave_all<R_SUM>(acc_r);
+      // the two logs of the row in one call: lane 1 takes s2, every other lane the weight ratio
+      const double lg = log_tab(lane == 1 ? s2 : div_fast(tail_ratio, total), tb.lt);
+      loo = lane_value(lg, 0) - m;
+      lppd = ((lane_value(lg, 1) + lppd_shift) - R) + ((-mn) - logS);       // loo.py:329-337
+      if ((!(total > 1e-280) || !isfinite(loo) || !isfinite(lppd)) && !(dbgs & 63)) slow = true;
+    }
+  }
+}
+
 // LW = false: LOO mode (input = log-likelihood, raw = -ll; outputs k-hat, loo_i, lppd_i)
 // LW = true:  weights mode (input = log ratios, raw = input; outputs k-hat and the normalised smoothed
 //             log-weights, psis.py:78-111): the row stays in its registers until the weights are stored
-template <typename T, int VEC, bool LW, typename SM>
-__device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParams& F, SM& sm, const WaveTables& tb, const int64_t r,
+template <typename T, int VEC, bool LW, typename SM, typename TB>
+__device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParams& F, SM& sm, const TB& tb, const int64_t r,
                                             T (&v)[kWaveSlots], const T* rp_next) {
   constexpr int EPT = kWaveSlots;
   constexpr int NQ = EPT / VEC;
+  constexpr int kCand = SM::Caps::kCand, kSa = SM::Caps::kSa;  // LDS capacities of this instantiation
   const int lane = wave_lane();
   // parameters arrive by reference (memory): read each once into scalar registers
   const int S = __builtin_amdgcn_readfirstlane(P.n_draws);
@@ -378,8 +802,8 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     // rides in the scalar append offset / the precomputed dump address instead of costing a vector
     // add per draw.
     const unsigned cand0 = lds_addr(sm.cand);
-    const unsigned dump8 = cand0 + (unsigned)(kCandCap + kWave + lane) * 8u;  // this lane's dump slot
-    const unsigned lim8 = cand0 + 8u * kCandCap;
+    const unsigned dump8 = cand0 + (unsigned)(kCand + kWave + lane) * 8u;  // this lane's dump slot
+    const unsigned lim8 = cand0 + 8u * kCand;
     unsigned next8 = cand0;                               // address of the next append (unclamped)
     unsigned base8 = cand0;                               // min(next8, lim8)
     // Software pipeline, kPF draws deep: stage A of draw i+kPF (shift, range reduction, table read,
@@ -425,7 +849,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         asm("" : "+v"(pos8));  // computed by every lane: a select below, not a divergent region
         lds_store(cand ? pos8 : dump8, x);
         if constexpr (LW)  // draw index of the candidate: VEC * (lane + 64 q) + e for slot i = q VEC + e
-          sm.ids[cand ? ((pos8 - cand0) >> 3) : (unsigned)(kCandCap + kWave + lane)] =
+          sm.ids[cand ? ((pos8 - cand0) >> 3) : (unsigned)(kCand + kWave + lane)] =
               (unsigned short)(VEC * lane + (VEC * kWave * (i / VEC) + i % VEC));
         {  // next8 += 8 * popcount(cm) in two scalar ops (the compiler would re-associate it into four)
           const unsigned pc = (unsigned)__popcll(cm);
@@ -460,367 +884,11 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     if (dbgs & 4) {
       loo = s1;
       lppd = s2;
-    } else if ((int)ncand < M + 1 || ncand > (unsigned)kCandCap) {
+    } else if ((int)ncand < M + 1 || ncand > (unsigned)kCand) {
       slow = true;  // the speculative threshold missed (too few / too many draws above it)
     } else {
-      // ---- 3. histogram of the candidate list, suffix scan (8 bins per lane) ---------------------
-      PLA_PHASE(4);
-      unsigned one = 1u;
-      asm volatile("" : "+v"(one));
-      // four list entries per lane and trip: the LDS reads go out together instead of one round trip each
-      for (unsigned c0 = lane; c0 < ncand; c0 += 4 * kWave) {
-        double xs[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned c = c0 + u * kWave;
-          xs[u] = sm.cand[c < ncand ? c : c0];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned c = c0 + u * kWave;
-          atomicAdd(&sm.hist[(key_of(xs[u]) - k1) >> sh], c < ncand ? one : 0u);  // past the end: add 0
-        }
-      }
-      wave_sync();
-      PLA_PHASE(5);
-      int bstar = 0, C1 = 0;
-      {
-        unsigned c[8];
-        unsigned tot = 0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const uint4 h = *reinterpret_cast<const uint4*>(&sm.hist[8 * lane + 4 * i]);
-          c[4 * i] = h.x; c[4 * i + 1] = h.y; c[4 * i + 2] = h.z; c[4 * i + 3] = h.w;
-          tot += h.x + h.y + h.z + h.w;
-        }
-        // inclusive prefix sum over the 64 lanes with DPP adds (no LDS round trips), then suffix = total - prefix
-        unsigned pre = tot;
-        pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)tot, 0x111, 0xF, 0xF, true);   // row_shr:1
-        pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)tot, 0x112, 0xF, 0xF, true);   // row_shr:2
-        pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)tot, 0x113, 0xF, 0xF, true);   // row_shr:3
-        pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x114, 0xF, 0xE, false);  // row_shr:4, banks 1-3
-        pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x118, 0xF, 0xC, false);  // row_shr:8, banks 2-3
-        pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x142, 0xA, 0xF, false);  // row_bcast:15
-        pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x143, 0xC, 0xF, false);  // row_bcast:31
-        const unsigned all = (unsigned)__builtin_amdgcn_readlane((int)pre, kWave - 1);
-        const unsigned suf = all - pre + tot;  // this lane's bins and everything above
-        unsigned a = suf - tot;  // candidates in bins owned by higher lanes
-        int fb = -1, fc = 0;
-        unsigned st[8];
-#pragma unroll
-        for (int i = 7; i >= 0; --i) {
-          st[i] = a;
-          if ((unsigned)M >= a && (unsigned)M < a + c[i]) {
-            fb = 8 * lane + i;
-            fc = (int)(a + c[i]);
-          }
-          a += c[i];
-        }
-        *reinterpret_cast<uint4*>(&sm.start[8 * lane]) =
-            make_uint4(st[0] | (st[1] << 16), st[2] | (st[3] << 16), st[4] | (st[5] << 16), st[6] | (st[7] << 16));
-        const unsigned long long who = __ballot(fb >= 0);
-        const int src = __ffsll((long long)who) - 1;
-        bstar = __builtin_amdgcn_readlane(fb, src);
-        C1 = __builtin_amdgcn_readlane(fc, src);
-      }
-      wave_sync();
-      if (C1 > kWaveCap) {
-        slow = true;
-      } else {
-        // ---- 4. candidates at/above the boundary bin -> sa, grouped by bin (descending bins) --------
-        PLA_PHASE(6);
-        const int kstar = k1 + (bstar << sh);
-        for (unsigned c0 = lane; c0 < ncand; c0 += 4 * kWave) {
-          double xs[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const unsigned c = c0 + u * kWave;
-            xs[u] = sm.cand[c < ncand ? c : c0];
-          }
-          unsigned short idv[4] = {0, 0, 0, 0};
-          if constexpr (LW) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const unsigned c = c0 + u * kWave;
-              idv[u] = sm.ids[c < ncand ? c : c0];
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const unsigned c = c0 + u * kWave;
-            const double x = xs[u];
-            const int k = key_of(x);
-            if (c < ncand && k >= kstar) {
-              const int b = (k - k1) >> sh;
-              const unsigned slot = sm.start[b] + (atomicSub(&sm.hist[b], 1u) - 1u);
-              sm.sa[slot] = x;
-              if constexpr (LW) sm.sa_id[slot] = idv[u];
-            }
-          }
-        }
-        if (lane < 4) sm.sa[C1 + lane] = -INF;  // sentinels for the 4-wide reads of the ranking loop
-        wave_sync();
-        PLA_PHASE(7);
-        double* sb = sm.cand;  // the list is consumed: its storage now holds the sorted candidates
-        // ---- 5. exact descending rank inside each bin (ties: arbitrary, the sums do not care) --
-        for (int c = lane; c < C1; c += kWave) {
-          const double x = sm.sa[c];
-          const int b = (key_of(x) - k1) >> sh;
-          const int lo = (int)sm.start[b];
-          const int hi = (b > 0) ? (int)sm.start[b - 1] : C1;
-          int cnt = 0, same = 0;
-          // four neighbours per trip (one LDS round trip): entries past the bin are smaller values of
-          // lower bins, entries past the end are -inf sentinels, so neither counts
-          for (int c2 = lo; c2 < hi; c2 += 4) {
-            double x2[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) x2[u] = sm.sa[c2 + u];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              cnt += (x2[u] > x) ? 1 : 0;
-              same += (x2[u] == x) ? 1 : 0;  // counts the element itself
-            }
-          }
-          if (__ballot(same > 1) != 0ull) {  // duplicates (repeated draws): order them by position
-            if (same > 1)
-              for (int c2 = lo; c2 < c; ++c2) cnt += (sm.sa[c2] == x) ? 1 : 0;
-          }
-          sb[lo + cnt] = x;
-          if constexpr (LW) sm.sb_id[lo + cnt] = sm.sa_id[c];
-        }
-        wave_sync();
-        // ---- cutoff (psis.py:135-141); R < 690: the log(DBL_MIN) floor cannot bind -------------
-        PLA_PHASE(8);
-        const double xcut = sb[M];
-        int n = M;
-        while (n > 0 && sb[n - 1] == xcut) --n;  // ties at the cutoff leave the tail
-        const double e_cut = exp_tab(xcut, tb.tab);
-        double acc_t = 0.0, acc_r = 0.0;  // (sum w' - sum e) and sum w'/e over the tail
-        bool smoothed = false;
-        if (n > 4 && !(dbgs & 8)) {
-          wave_sync();
-          // y ascending (psis.py:146-147), stored with the pair sums / products the fit loop eats
-          // (the reciprocals e^-x of the same range reduction are kept for the weight ratios below)
-          double* inv_e = sb + kWaveCap + kWave;  // beyond the sorted candidates and the pair data
-          const int n32 = (n + 31) & ~31;  // padded with y = 0 (factor 1) so that the fit runs whole trips only
-          // Straight-line code for 3 (n <= 192, the usual case) or 4 elements per lane: the independent
-          // exp chains interleave instead of running one LDS round trip + ~20 dependent fp64 ops at a time.
-          // Every slot up to 64 U is written (zeros past n), so the later loops need no bounds either.
-          const bool three = n32 <= 3 * kWave;
-          const auto y_pass = [&](auto UC) {
-            constexpr int U = decltype(UC)::value;
-            double xv[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-              const int j = lane + kWave * u;
-              xv[u] = sb[j < n ? n - 1 - j : 0];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-              const int j = lane + kWave * u;
-              double ep, en;
-              exp_pair(xv[u], tb.tab, ep, en);
-              sm.sa[j] = j < n ? ep - e_cut : 0.0;
-              inv_e[j] = en;
-            }
-          };
-          if (three) y_pass(std::integral_constant<int, 3>{}); else y_pass(std::integral_constant<int, 4>{});
-          wave_sync();
-          const double* y = sm.sa;
-          const double nn = (double)n;
-          // (1 - b y0)(1 - b y1) = 1 - b (y0 + y1) + b^2 y0 y1: pair sums / products once per row
-          {
-            double2 yy[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) yy[u] = *reinterpret_cast<const double2*>(y + 2 * (lane + kWave * u));
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-              *reinterpret_cast<double2*>(&sb[2 * (lane + kWave * u)]) = make_double2(yy[u].x + yy[u].y, yy[u].x * yy[u].y);
-          }
-          wave_sync();
-          const double* yp = sb;
-          // ---- 6. GPD fit (psis.py:163-208), lane j <-> grid point b_j -------------------------
-          PLA_PHASE(9);
-          const int mest = 30 + isqrt_i(n);
-          const double yq = y[((n + 2) >> 2) - 1];
-          const double yn = y[n - 1];
-          const bool act = lane < mest;
-          // psis.py:186: 1 - sqrt(m_est / (j - 0.5)); host table for the usual n == M
-          double b = (mest == mestM) ? bgrid[lane] : 1.0 - sqrt((double)mest / ((double)(lane + 1) - 0.5));
-          b = div_fast(b, 3.0 * yq);   // psis.py:187
-          b += recip_fast(yn);         // psis.py:188
-          const double b_first = lane_value(b, 0);  // most negative grid point
-          const double b_last = lane_value(b, mest - 1);
-          const double fbig = fma(-b_first, yn, 1.0), fsmall = fma(-b_last, yn, 1.0);
-          const bool wide = (fbig < 0x1p30) && (fsmall > 0x1p-30);  // 16 factors per accumulator between renorms
-          // lanes whose b_j is ~0 would lose the low bits of b_j*y in 1 - b_j*y: carry them along
-          const bool tiny = __ballot(act && fabs(b * yn) < 0.015625) != 0ull;
-          PLA_PHASE(10);
-          ProdAcc acc, acc2;
-          acc.init();
-          acc2.init();
-          const double nb = -b;
-          double corr = 0.0;
-          int i = 0;
-          if (wide && !tiny) {
-            // factors within 2^+-15: four trips (8 pair factors per accumulator each) fit between renorms
-            const bool narrow = (fbig < 0x1p15) && (fsmall > 0x1p-15);
-            for (; i < n32; i += 32) {
-#pragma unroll
-              for (int u = 0; u < 32; u += 4) {
-                const double2 pa = *reinterpret_cast<const double2*>(yp + i + u);
-                const double2 pb = *reinterpret_cast<const double2*>(yp + i + u + 2);
-                acc.mul(fma(nb, fma(nb, pa.y, pa.x), 1.0));
-                acc2.mul(fma(nb, fma(nb, pb.y, pb.x), 1.0));
-              }
-              if (!narrow || (i & 96) == 96) {
-                acc.renorm();
-                acc2.renorm();
-              }
-            }
-            acc.renorm();
-            acc2.renorm();
-          } else {
-            for (; i < n; ++i) {
-              const double yi = y[i];
-              const double f = fma(nb, yi, 1.0);
-              corr += fma(nb, yi, 1.0 - f) * __builtin_amdgcn_rcp(f);  // rounding error of f, relative
-              acc.mul(f);
-              acc.renorm();
-            }
-          }
-          PLA_PHASE(11);
-          acc.m *= acc2.m;
-          acc.e += acc2.e;
-          const double rn = recip_fast(nn);
-          const double kj = ((log_tab(acc.m, tb.lt) + (double)acc.e * kLn2) + corr) * rn;   // psis.py:190
-          const double ls = nn * (log_tab(act ? -div_fast(b, kj) : 1.0, tb.lt) - kj - 1.0);             // psis.py:191
-          const double lmax = wave_all<R_MAX>(act ? ls : -INF);
-          // NaN anywhere, or max = +-inf: every weight is NaN in the reference -> nothing is kept
-          const bool anynan = (__ballot(act && (ls != ls)) != 0ull) || !(fabs(lmax) < INF);
-          double w = act ? exp_neg(ls - lmax, tb.tab) : 0.0;                          // psis.py:192
-          const double se = wave_all<R_SUM>(w);
-          w = anynan ? qnan() : w * recip_fast(se);
-          const bool keep = act && (w >= 10.0 * kEps);                                // psis.py:194-197
-          const double sw = wave_all<R_SUM>(keep ? w : 0.0);
-          const double bw = wave_all<R_SUM>(keep ? b * w : 0.0);
-          const double b_post = (sw > 0.0) ? div_fast(bw, sw) : 0.0;                  // psis.py:198,201
-          // psis.py:203: mean_i log1p(-b_post*y_i) as the log of per-lane products
-          PLA_PHASE(12);
-          double pr;
-          {  // y is zero past n: no bounds
-            const double f0 = fma(-b_post, y[lane], 1.0), f1 = fma(-b_post, y[lane + kWave], 1.0);
-            const double f2 = fma(-b_post, y[lane + 2 * kWave], 1.0);
-            pr = f0 * f1 * f2;
-            if (!three) pr *= fma(-b_post, y[lane + 3 * kWave], 1.0);
-          }
-          const double k_post = wave_all<R_SUM>(log_tab(pr, tb.lt)) * rn;
-          const double sigma = -k_post / b_post;                                      // psis.py:205
-          khat = (nn * k_post + 5.0) / (nn + 10.0);                                   // psis.py:206
-          PLA_PHASE(13);
-          if (isfinite(khat)) {
-            const double* inv_e = sb + kWaveCap + kWave;
-            double* wtail = sb + kWaveCap + kWave;  // weights mode: overwrites inv_e (not needed there)
-            smoothed = true;
-            const double rk = 1.0 / khat;
-            const bool ktiny = fabs(khat) < kEps;
-            if (sigma > 0.0 && !ktiny && n == M) {
-              // the usual case, straight-line: w_j = sigma/k (e^{z_j} - 1) + e_cut with z_j = -k log1p(-p_j) from
-              // the host table (psis.py:153,218-221).  e^z - 1 by subtraction is accurate to 1e-16 ABSOLUTE,
-              // which is all the sum w_j + e_cut can see.
-              const double coef = sigma * rk, off = e_cut - coef;
-              const auto smooth_pass = [&](auto UC) {
-                constexpr int U = decltype(UC)::value;
-                double ez[U], yv[U], iv[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                  const int j = lane + kWave * u;
-                  const double z = fmin(-khat * l1tab[j < n ? j : 0], 700.0);
-                  ez[u] = exp_tab(z, tb.tab);
-                  yv[u] = y[j];
-                  iv[u] = inv_e[j];
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                  const int j = lane + kWave * u;
-                  double wj = fma(ez[u], coef, off);  // exp(log(q + e_cut)), psis.py:155
-                  wj = fmin(wj, 1.0);                 // psis.py:157
-                  const double ej = yv[u] + e_cut;
-                  acc_t += (j < n) ? wj - ej : 0.0;
-                  acc_r += (j < n) ? wj * iv[u] : 0.0;
-                  if constexpr (LW) wtail[j] = wj;  // (clipped) smoothed weight of tail element j
-                }
-              };
-              if (three) smooth_pass(std::integral_constant<int, 3>{}); else smooth_pass(std::integral_constant<int, 4>{});
-            } else {
-              for (int j = lane; j < n; j += kWave) {
-                // log1p(-p_j), p_j = (j + 0.5)/n (psis.py:153): host table when n == M
-                const double l1 = (n == M) ? l1tab[j] : log_fast(1.0 - ((double)j + 0.5) * rn);
-                double q;
-                if (sigma <= 0.0) {
-                  q = qnan();                                                           // psis.py:214-215
-                } else {
-                  q = ktiny ? -l1 : expm1_tab(-khat * l1, tb.tab) * rk;                 // psis.py:218-221
-                  q *= sigma;
-                }
-                double wj = q + e_cut;   // exp(log(q + e_cut)), psis.py:155
-                if (wj > 1.0) wj = 1.0;  // psis.py:157
-                const double ej = y[j] + e_cut;
-                acc_t += wj - ej;
-                acc_r = fma(wj, inv_e[j], acc_r);
-                if constexpr (LW) wtail[j] = wj;
-              }
-            }
-          }
-        }
-        // total = sum_nontail e^x + sum_tail w' = (s1 - sum_tail e) + sum_tail w'
-        PLA_PHASE(14);
-        const double total = wave_all<R_SUM>(s1 + acc_t);
-        if constexpr (LW) {
-          // ---- weights mode: lw_s = x_s - log(total) for every draw, the smoothed tail at its positions ----
-          const double L = log_tab(total, tb.lt);  // psis.py:158 (_logsumexp of the shifted, smoothed row)
-          if (!(total > 1e-280) || !isfinite(L)) {
-            slow = true;
-          } else {
-            typedef int v4i __attribute__((ext_vector_type(4)));
-            T* orow = reinterpret_cast<T*>(P.lw_out) + r * (int64_t)S;
-            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(orow, 0, S * (int)sizeof(T), 0x00020000);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-              if (q <= qfull) {  // later vectors lie past the row (stores past the end are dropped anyway)
-                v4i t;
-                if constexpr (VEC == 2) {
-                  const double a0 = ((double)v[2 * q] - m) - L, a1 = ((double)v[2 * q + 1] - m) - L;
-                  t[0] = __double2loint(a0); t[1] = __double2hiint(a0);
-                  t[2] = __double2loint(a1); t[3] = __double2hiint(a1);
-                } else {
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) t[e] = __float_as_int((float)(((double)v[4 * q + e] - m) - L));
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(t, ro, lane * 16, q * (kWave * 16), 0);
-              }
-            }
-            if (smoothed) {
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the patches below must land after the row
-              const double* wtail = sb + kWaveCap + kWave;
-              for (int j = lane; j < n; j += kWave) {
-                const int id = (int)sm.sb_id[n - 1 - j];
-                orow[id] = (T)(log_tab(wtail[j], tb.lt) - L);  // psis.py:155-158
-              }
-            }
-          }
-        } else {
-          s2 = wave_all<R_SUM>(s2);
-          // loo_i = -m - L + log(tail_ratio),  L = log(total) (psis.py:158; loo.py:289,319-324): one log
-          double tail_ratio = (double)S;
-          if (smoothed) tail_ratio = (double)(S - n) + wave_all<R_SUM>(acc_r);
-          // the two logs of the row in one call: lane 1 takes s2, every other lane the weight ratio
-          const double lg = log_tab(lane == 1 ? s2 : div_fast(tail_ratio, total), tb.lt);
-          loo = lane_value(lg, 0) - m;
-          lppd = (lane_value(lg, 1) - R) + ((-mn) - logS);                      // loo.py:329-337
-          if ((!(total > 1e-280) || !isfinite(loo) || !isfinite(lppd)) && !(dbgs & 63)) slow = true;
-        }
-      }
+      wave_back<T, VEC, LW, SM, TB>(P, sm, tb, r, v, lane, S, M, mestM, logS, dbgs, m, mn, R, 0.0, s1, s2, ncand, k1, sh,
+                                    magic, c256, qfull, qrem, slow, khat, loo, lppd);
     }
   }
   // the next row starts streaming into the (now dead) row registers while the outputs are stored and
@@ -844,11 +912,13 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
 // The per-row body is deliberately NOT inlined into the row loop: inlined, LLVM hoists every
 // loop-invariant constant, mask and offset of the later phases above the loop, where they sit on
 // top of the 128 row registers and spill.
-template <typename T, int VEC, bool LW>
-__global__ __launch_bounds__(kWave * kWavesPerBlock, PLA_MIN_WAVES_PER_SIMD) void wave_loo_kernel(RowsParams P, FastParams F) {
-  using SM = std::conditional_t<LW, WaveSmemLW, WaveSmem>;
+template <typename T, int VEC, bool LW, class CAP>
+__global__ __launch_bounds__(kWave * CAP::kWaves, PLA_MIN_WAVES_PER_SIMD) void wave_loo_kernel(RowsParams P, FastParams F) {
+  using SM = std::conditional_t<LW, WaveSmemLWT<CAP>, WaveSmemT<CAP>>;
+  using TB = WaveTablesT<CAP>;
+  constexpr int kWavesPerBlock = CAP::kWaves;
   __shared__ __attribute__((aligned(16))) SM scratch[kWavesPerBlock];
-  __shared__ __attribute__((aligned(16))) WaveTables tb;
+  __shared__ __attribute__((aligned(16))) TB tb;
   const int tid = threadIdx.x;
   for (int j = tid; j < kTabN; j += kWave * kWavesPerBlock) exp_table_entry(tb.tab, j);
   for (int j = tid; j < kLogTabN; j += kWave * kWavesPerBlock) log_table_entry(tb.lt, j);
@@ -867,7 +937,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, PLA_MIN_WAVES_PER_SIMD) voi
 #endif
   for (int64_t r = w0; r < P.n_obs; r += nw) {
     const int64_t rn = r + nw;
-    wave_loo_row<T, VEC, LW, SM>(P, F, sm, tb, r, v, rn < P.n_obs ? base + rn * P.stride_obs : nullptr);
+    wave_loo_row<T, VEC, LW, SM, TB>(P, F, sm, tb, r, v, rn < P.n_obs ? base + rn * P.stride_obs : nullptr);
   }
 #if PLA_WAVE_ABLATE
   if (blockIdx.x == 0 && tid == 0) {  // core clock against the 100 MHz real-time counter

@@ -274,6 +274,27 @@ def test_fast_and_slow_rows_in_one_matrix(eng):
     assert int(res["agg"][5]) == int(np.sum(~np.isfinite(ref["khat"])))
 
 
+@pytest.mark.parametrize("S", [4000, 8000])
+def test_rows_with_a_dominant_draw(eng, S):
+    """One draw far above the rest: the smoothed tail is much lighter than the raw one, the regime where
+    'sum of all exponentials minus the tail's' cancels.  Those rows must still equal the reference."""
+    rng = np.random.default_rng(3)
+    mags = [0.0, 2.0, 5.0, 8.0, 10.0, 15.0, 20.0, 40.0, 100.0, 300.0, 600.0]
+    ll = -0.5 * rng.exponential(size=(len(mags), S)) - 1.0
+    for i, g in enumerate(mags):
+        if g:
+            ll[i, (S // 2 + 997 * i) % S] = ll[i].min() - g
+    M = orc.tail_count(S, 1.0)
+    ref = orc.loo_arrays(ll, 1.0)
+    res = eng.psis_loo(ll, M, "psis", 1.0, 0.7)
+    close(res["diag"], ref["khat"], what="khat")
+    close(res["loo_i"], ref["loo_i"], what="loo_i")
+    close(res["lppd_i"], ref["lppd_i"], what="lppd_i")
+    lw_ref, _ = orc.psislw(-ll, 1.0)
+    lw, _ = eng.importance_weights(-ll, M, "psis")
+    close(lw, lw_ref, what="lw")
+
+
 def test_weights_fast_and_slow_rows_in_one_matrix(eng):
     """psislw through the wave kernel (weights mode) with rows it has to hand to the general kernel mixed
     in: every row's smoothed log-weights and k-hat equal the oracle; f32 keeps its dtype."""
@@ -343,6 +364,34 @@ def test_weights_device_tensors_full_size(eng):
     ref_lw, ref_k = orc.psislw(logw[idx].cpu().numpy(), 1.0)
     close(k.cpu().numpy()[idx], ref_k, what="khat")
     close(lw.cpu().numpy()[idx], ref_lw, what="lw")
+
+
+@pytest.mark.parametrize("S,N,reff,dt", [(8000, 150, 1.0, np.float64), (20000, 60, 1.0, np.float32),
+                                         (4096 + 256, 40, 1.0, np.float64), (12288, 30, 0.5, np.float64),
+                                         (4000, 80, 0.3, np.float64), (2000, 64, 0.35, np.float64)])
+def test_chunked_kernel_vs_oracle(eng, S, N, reff, dt):
+    """Rows longer than one register chunk and / or tail counts above 250 (pla_chunked.h), with rows the
+    kernel must hand to the general one mixed in, and the row maximum placed in a late chunk."""
+    rng = np.random.default_rng(S + N)
+    k = rng.uniform(0.05, 1.3, size=N)
+    ll = (-k[:, None] * rng.exponential(size=(N, S)) + rng.normal(size=(N, 1))).astype(np.float64)
+    ll[1, S - 7] = ll[1].min() - 3.0          # the largest -ll of the row sits in the last chunk
+    ll[2, S // 2] = ll[2].min() - 40.0        # ... far above the provisional shift
+    ll[3, 5] = np.nan
+    ll[4, S - 1] = -np.inf
+    ll[5] *= 300.0                            # range above 690 nats
+    ll[6] = -1.0                              # constant row
+    ll[7, : S // 2] = np.round(ll[7, : S // 2] * 4.0) / 4.0   # ties
+    ll = ll.astype(dt)
+    ref = orc.loo_arrays(ll.astype(np.float64), reff)
+    M = orc.tail_count(S, reff)
+    res = eng.psis_loo(ll, M, "psis", 1.0, ref["good_k"])
+    close(res["diag"], ref["khat"], what="khat")
+    close(res["loo_i"], ref["loo_i"], what="loo_i")
+    close(res["lppd_i"], ref["lppd_i"], what="lppd_i")
+    n_slow = int(res["agg"][7])
+    assert 4 <= n_slow <= 12, n_slow          # nan, -inf, wide, constant, dominant draw (+ threshold misses / ties)
+    np.testing.assert_allclose(res["agg"][1], ref["elpd_loo"], rtol=RTOL)
 
 
 def test_general_kernel_agrees_with_fast_path():
