@@ -53,7 +53,21 @@ def main():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0003)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--config", default=None, choices=["C2", "C3", "C4", "C5"],
+                    help="BASELINE.json preset (per-GPU shard): C2 = 1e5 x 4000 f64, C3 / C4 = 1e6 x 4000 f64 per GPU, "
+                         "C5 = 125 000 x 20 000 f32 per GPU with 30 %% heavy-tailed rows")
     args = ap.parse_args()
+    heavy = (0.0, 0.0)
+    k_hi = 0.60
+    if args.config == "C2":
+        args.obs, args.draws, args.dtype, args.seed = 100_000, 4000, "f64", 0x5EED0002
+    elif args.config in ("C3", "C4"):
+        args.obs, args.draws, args.dtype = 1_000_000, 4000, "f64"
+        args.seed = 0x5EED0003 if args.config == "C3" else 0x5EED0004
+    elif args.config == "C5":  # 70 % rows k ~ U(0.05, 0.5), 30 % rows k ~ U(1.0, 1.3)
+        args.obs, args.draws, args.dtype, args.seed = 125_000, 20000, "f32", 0x5EED0005
+        heavy, k_hi = (1.0, 1.3), 0.5
+    label = args.config or ("C3" if (args.draws, args.dtype, args.obs) == (4000, "f64", 1_000_000) else "custom")
 
     import numpy as np
     import torch
@@ -79,7 +93,7 @@ def main():
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
     esz = 8 if args.dtype == "f64" else 4
     ll = torch.empty((n_local, S), dtype=tdt, device=dev)
-    eng.fill_synthetic(ll, seed=args.seed, row0=rank * n_local, k_lo=0.05, k_hi=0.60)
+    eng.fill_synthetic(ll, seed=args.seed, row0=rank * n_local, k_lo=0.05, k_hi=k_hi, heavy_lo=heavy[0], heavy_hi=heavy[1])
     torch.cuda.synchronize()
 
     reff = 1.0
@@ -142,7 +156,7 @@ def main():
         "dtype": args.dtype,
         "data": "synthetic",
         "config": {
-            "workload": f"C3: synthetic {args.dtype} log_lik S={S} draws x N={n_local} observations per GPU, "
+            "workload": f"{label}: synthetic {args.dtype} log_lik S={S} draws x N={n_local} observations per GPU, "
                         f"PSIS-LOO reff=1 (M={M}), device-resident, obs-sharded",
             "obs_per_gpu": n_local,
             "draws": S,
