@@ -191,11 +191,14 @@ static hipError_t launch_one(const RowsParams& p, hipStream_t stream) {
 
 // Speculative threshold of the wave kernel: the kq-th smallest (roughly) of the 64 per-lane maxima
 // over the first gsz register slots.  For exchangeable draws a draw lies below it with probability F,
-// F^gsz = kq/64.  Pick (gsz, kq) so that ~2.6(M+1) draws lie above, with kq large enough for the order
+// F^gsz = kq/64.  Pick (gsz, kq) so that ~2.2(M+1) draws lie above, with kq large enough for the order
 // statistic to be stable.  Returns false when no setting fits (the general kernel takes the call).
 // `cand_cap`: capacity of the LDS candidate list; only the first min(S, 4096) draws feed the maxima.
 static bool wave_threshold_params(int S, int vec, int M, int* gsz_out, int* kq_out, int cand_cap = kCandCap) {
-  const double target = 2.6 * (M + 1);
+#ifndef PLA_CAND_MULT
+#define PLA_CAND_MULT 2.2
+#endif
+  const double target = PLA_CAND_MULT * (M + 1);
   if (target > 0.62 * cand_cap || target >= 0.5 * S) return false;
   const double F = 1.0 - target / S;
   const int S0 = S < kWave * kWaveSlots ? S : kWave * kWaveSlots;

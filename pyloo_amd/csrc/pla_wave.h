@@ -46,6 +46,12 @@ namespace pla {
 #ifndef PLA_WAVES_PER_BLOCK
 #define PLA_WAVES_PER_BLOCK 4
 #endif
+#ifndef PLA_BISECT_ITERS
+#define PLA_BISECT_ITERS 9
+#endif
+#ifndef PLA_SWEEP_DEPTH
+#define PLA_SWEEP_DEPTH 3
+#endif
 #ifndef PLA_MIN_WAVES_PER_SIMD
 #define PLA_MIN_WAVES_PER_SIMD 2
 #endif
@@ -741,7 +747,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   {
     double lo = wave_all<R_MIN>(gs), hi = m;
 #pragma unroll 1
-    for (int it = 0; it < 9; ++it) {  // 2^-9 of the spread of the group maxima: a handful of candidates
+    for (int it = 0; it < PLA_BISECT_ITERS; ++it) {  // 2^-iters of the spread of the group maxima: a handful of candidates
       const double mid = 0.5 * (lo + hi);
       const int below = __popcll(__ballot(gs < mid));
       if (below >= kq) hi = mid; else lo = mid;
@@ -809,7 +815,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     // Software pipeline, kPF draws deep: stage A of draw i+kPF (shift, range reduction, table read,
     // candidate append) is issued before stage B of draw i (polynomial, accumulate), so the LDS
     // latency of the table read is covered by the arithmetic of the draws in between.
-    constexpr int kPF = 3;
+    constexpr int kPF = PLA_SWEEP_DEPTH;
     double px[kPF], pt[kPF];
     int4 ptt[kPF];
 #pragma unroll
