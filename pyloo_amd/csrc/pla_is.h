@@ -1,0 +1,147 @@
+// Streaming LOO pass for the two importance-sampling methods without a tail fit:
+//   SIS  (sis.py:86-106)   lw = x - LSE(x),                         x = -ll - max(-ll)
+//   TIS  (tis.py:91-120)   lw = x_t - LSE(x_t),  x_t = min(x, LSE(x) - log S + 0.5 log S)
+// with the diagnostic ESS = 1 / sum_s exp(lw_s)^2 (sis.py:104-105, tis.py:118-119) and, fused as in
+// pla_psis_loo, loo_i = LSE_s(lw_s + ll_s) (loo.py:289,319-324) and lppd_i (loo.py:329-337).
+// In terms of three sums over the row (all of positive terms, nothing cancels):
+//   A = sum e^x_t,  B = sum e^(2 x_t),  D = sum e^(x_t - x),  C = sum e^-x
+//   ESS = A^2 / B,   loo_i = -max - log A + log D,   lppd_i = log C - max - log S
+// (SIS: x_t = x, D = S).  One wavefront per observation, the row in its registers (S <= 4096, unit
+// draw stride, 16-byte aligned rows): one HBM read; TIS makes a second pass over the registers, the
+// next row streams in behind the last pass.  Rows with non-finite entries or more than 690 nats of
+// range go to the general kernel through the device list, as in pla_wave.h.
+#pragma once
+
+#include "pla_wave.h"
+
+namespace pla {
+
+template <typename T, int VEC, bool TIS>
+__global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void is_wave_kernel(RowsParams P, FastParams F) {
+  __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];
+  __shared__ __attribute__((aligned(16))) double lt[2 * kLogTabN];
+  constexpr int EPT = kWaveSlots, NQ = EPT / VEC;
+  const int tid = threadIdx.x;
+  for (int j = tid; j < kTabN; j += kWave * kWavesPerBlock) exp_table_entry(tab, j);
+  for (int j = tid; j < kLogTabN; j += kWave * kWavesPerBlock) log_table_entry(lt, j);
+  __syncthreads();
+  const int lane = wave_lane();
+  const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int S = P.n_draws;
+  constexpr bool tis = TIS;
+  const double log_S = log((double)S);
+  const T* base = reinterpret_cast<const T*>(P.in);
+  const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + wv, nw = (int64_t)gridDim.x * kWavesPerBlock;
+  T v[kWaveSlots];
+  if (w0 < P.n_obs) issue_row_loads<T, VEC>(v, base + w0 * P.stride_obs, S);
+  for (int64_t r = w0; r < P.n_obs; r += nw) {
+    const int64_t rn = r + nw;
+    const T* rp_next = rn < P.n_obs ? base + rn * P.stride_obs : nullptr;
+    const __amdgpu_buffer_rsrc_t rs_next = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(rp_next ? rp_next : base), 0, rp_next ? S * (int)sizeof(T) : 0, 0x00020000);
+    const int nvec = __builtin_amdgcn_readfirstlane(P.n_draws) / VEC;  // (kept inside the loop: see pla_waic.h)
+    const int qfull = nvec / kWave, qrem = nvec - qfull * kWave;
+    // slots past the row: copies of the lane's first vector, whose contribution is subtracted afterwards
+    pad_tail<T, VEC, NQ - 1, false>(v, qfull, qrem, (T)0);
+    const double ncopy = (double)((NQ - qfull) - (lane < qrem ? 1 : 0));
+    double first[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) first[e] = -(double)v[e];  // raw = -ll
+    // ---- statistics ------------------------------------------------------------------------------
+    double mx, mn;
+    {
+      T cur = (T)(-pinf()), vmx = (T)(-pinf());
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        cur = vmax_nc<true>(v[i], cur);
+        vmx = vmax_nc<false>(v[i], vmx);
+      }
+      mx = (double)cur;
+      mn = -(double)vmx;
+    }
+    const double m = wave_all<R_MAX>(mx);
+    mn = wave_all<R_MIN>(mn);
+    const double R = m - mn;
+    bool slow = !(R < kWaveMaxRange);  // also inf / NaN through the maximum or the minimum
+    double ess = 0.0, loo = 0.0, lppd = 0.0;
+    // ---- pass 1: A = sum e^x, B = sum e^2x (SIS), C = sum e^-x ------------------------------------
+    double sa = 0.0, sb = 0.0, sc = 0.0;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      double ep, en;
+      exp_pair((-(double)v[i]) - m, tab, ep, en);  // x in [-R, 0], R < 690; a NaN draw poisons the sums -> general kernel
+      sa += ep;
+      sb = fma(ep, ep, sb);
+      sc += en;
+      // pin the running sums: otherwise the scheduler starts all 64 independent exponentials at once and spills
+      if ((i & 1) == 1) asm volatile("" : "+v"(sa), "+v"(sb), "+v"(sc));
+      if constexpr (!tis)
+        if ((i % VEC) == VEC - 1) issue_row_vector<T, VEC>(v, rs_next, i / VEC);
+    }
+    {
+      double a0 = 0.0, b0 = 0.0, c0 = 0.0;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        double ep, en;
+        exp_pair(first[e] - m, tab, ep, en);
+        a0 += ep;
+        b0 = fma(ep, ep, b0);
+        c0 += en;
+      }
+      sa = fma(-ncopy, a0, sa);
+      sb = fma(-ncopy, b0, sb);
+      sc = fma(-ncopy, c0, sc);
+    }
+    double A = wave_all<R_SUM>(sa), B = 0.0, D = (double)S;
+    const double C = wave_all<R_SUM>(sc);
+    if constexpr (!tis) {
+      B = wave_all<R_SUM>(sb);
+    } else {
+      // ---- pass 2 (TIS): truncate at cut = LSE(x) - log S + 0.5 log S, sums of the truncated weights ----
+      const double cut = (log_tab(A, lt) - log_S) + 0.5 * log_S;  // tis.py:107-110
+      const double ecut = exp_tab(fmin(fmax(cut, -700.0), 700.0), tab);
+      double ta = 0.0, tb = 0.0, td = 0.0;
+      double m2 = m;  // laundered: otherwise the 64 shifted values of pass 1 are kept alive for this pass and spill
+      asm volatile("" : "+v"(m2));
+      const auto term = [&](double x, double& a, double& b, double& d) {
+        double ep, en;
+        exp_pair(x, tab, ep, en);
+        const bool tr = x > cut;
+        const double w = tr ? ecut : ep;
+        a += w;
+        b = fma(w, w, b);
+        d += tr ? ecut * en : 1.0;
+      };
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        term((-(double)v[i]) - m2, ta, tb, td);
+        if ((i & 1) == 1) asm volatile("" : "+v"(ta), "+v"(tb), "+v"(td));
+        if ((i % VEC) == VEC - 1) issue_row_vector<T, VEC>(v, rs_next, i / VEC);
+      }
+      double a0 = 0.0, b0 = 0.0, d0 = 0.0;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) term(first[e] - m2, a0, b0, d0);
+      A = wave_all<R_SUM>(fma(-ncopy, a0, ta));
+      B = wave_all<R_SUM>(fma(-ncopy, b0, tb));
+      D = wave_all<R_SUM>(fma(-ncopy, d0, td));
+    }
+    ess = div_fast(A * A, B);
+    const double lg = log_tab(lane == 1 ? C : (lane == 2 ? D : A), lt);
+    const double logA = lane_value(lg, 0), logC = lane_value(lg, 1), logD = lane_value(lg, 2);
+    loo = ((-m) - logA) + logD;
+    lppd = (logC - m) - log_S;
+    if (!isfinite(ess) || !isfinite(loo) || !isfinite(lppd)) slow = true;
+    if (lane == 0) {
+      if (slow) {
+        const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
+        F.slow_list[idx] = (unsigned)r;
+      } else {
+        if (P.diag) P.diag[r] = ess;
+        if (P.loo_i) P.loo_i[r] = P.scale_value * loo;
+        if (P.lppd_i) P.lppd_i[r] = lppd;
+      }
+    }
+  }
+}
+
+}  // namespace pla

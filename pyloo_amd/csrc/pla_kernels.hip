@@ -20,6 +20,7 @@
 #include "pla_wave.h"
 #include "pla_waic.h"
 #include "pla_chunked.h"
+#include "pla_is.h"
 
 namespace pla {
 
@@ -267,6 +268,27 @@ static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, hipStream
   return hipGetLastError();
 }
 
+// SIS / TIS in LOO mode: streaming kernel (pla_is.h) + the general kernel for the rows it declines
+template <typename T, int VEC>
+static hipError_t launch_is(const RowsParams& p, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return e;
+  FastParams f{0, 0, p.slow_list, p.counters, 0, nullptr, std::log((double)p.n_draws), nullptr, 0};
+  int64_t grid = (p.n_obs + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (grid > 2048 * 8 / kWavesPerBlock) grid = 2048 * 8 / kWavesPerBlock;
+  if (p.method == PLA_TIS)
+    hipLaunchKernelGGL((is_wave_kernel<T, VEC, true>), dim3((unsigned)grid), dim3(kWave * kWavesPerBlock), 0, stream, p, f);
+  else
+    hipLaunchKernelGGL((is_wave_kernel<T, VEC, false>), dim3((unsigned)grid), dim3(kWave * kWavesPerBlock), 0, stream, p, f);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  constexpr int BLOCK = 256;
+  int64_t g2 = p.n_obs < 1024 ? p.n_obs : 1024;
+  hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK, false>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap),
+                     stream, p);
+  return hipGetLastError();
+}
+
 template <typename T, bool LW>
 static hipError_t launch_typed(const RowsParams& p, hipStream_t stream) {
   constexpr int BLOCK = 256;
@@ -285,6 +307,9 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream) {
       }
     }
     if constexpr (!LW) {
+      if (path != 1 && unit && waligned && (p.method == PLA_SIS || p.method == PLA_TIS) && p.slow_list && p.counters &&
+          p.n_draws <= kWave * kWaveSlots && p.n_draws >= kWave * WVEC && p.n_obs <= 0xffffffffll)
+        return launch_is<T, WVEC>(p, stream);
       // rows beyond one register chunk or tails beyond the small kernel's LDS: the chunked kernel
       const int last_chunk = p.n_draws - ((p.n_draws - 1) / kChunkDraws) * kChunkDraws;
       if (path != 1 && unit && waligned && p.method == PLA_PSIS && p.slow_list && p.counters && p.l1_table &&

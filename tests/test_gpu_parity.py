@@ -154,6 +154,32 @@ def test_sis_tis(eng, method):
     assert res["agg"][6] == pytest.approx(ref["diag"].min(), rel=1e-9)
 
 
+@pytest.mark.parametrize("method", ["sis", "tis"])
+@pytest.mark.parametrize("S,dt", [(4000, np.float64), (3998, np.float64), (1024, np.float32), (256, np.float64)])
+def test_sis_tis_streaming_kernel(eng, method, S, dt):
+    """SIS / TIS LOO pass on the streaming wave kernel (pla_is.h), rows for the general kernel mixed in;
+    heavy-tailed rows so that the TIS truncation actually bites."""
+    rng = np.random.default_rng(S)
+    N = 150
+    k = rng.uniform(0.05, 1.5, size=N)
+    ll = -k[:, None] * rng.exponential(size=(N, S)) + rng.normal(size=(N, 1))
+    ll[2, 7] = np.nan
+    ll[3, S - 1] = -np.inf
+    ll[4] *= 300.0                      # range above 690 nats
+    ll[5] = -0.75                       # constant row: every weight 1/S
+    ll[6, S // 3] = ll[6].min() - 60.0  # one dominant draw
+    ll = ll.astype(dt)
+    ref = orc.loo_pointwise(ll.astype(np.float64), 1.0, method)
+    res = eng.psis_loo(ll, 0, method, 1.0, 0.7)
+    close(res["diag"], ref["diag"], what="ess")
+    close(res["loo_i"], ref["loo_i"], what="loo_i")
+    close(res["lppd_i"], ref["lppd_i"], what="lppd_i")
+    assert 2 <= int(res["agg"][7]) <= 6          # nan, -inf (+ the wide row and the dominant draw when their range exceeds 690 nats)
+    if method == "tis":
+        trunc = (np.exp(ref["lw"]).max(axis=1) < np.exp(orc.importance_weights(-ll.astype(np.float64), "sis", 1.0)[0]).max(axis=1) * 0.999)
+        assert trunc.sum() > 20                   # the truncation changed the largest weight in many rows
+
+
 def test_device_tensors_match_host(eng):
     import torch
 
