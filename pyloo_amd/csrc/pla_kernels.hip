@@ -247,7 +247,7 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, hipStream_t 
 }
 
 // long rows (chunks of 4096 draws) and / or tail counts up to 512: pla_chunked.h
-template <typename T, int VEC>
+template <typename T, int VEC, class CAP>
 static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
@@ -255,10 +255,10 @@ static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, hipStream
   while (root_ * root_ > p.tail_count) --root_;
   while ((root_ + 1) * (root_ + 1) <= p.tail_count) ++root_;
   FastParams f{gsz, kq, p.slow_list, p.counters, 0, p.l1_table, std::log((double)p.n_draws), p.l1_table + p.tail_count, 30 + root_};
-  constexpr int W = CapsBig::kWaves;  // 2 waves per workgroup, 2 workgroups per CU (LDS)
+  constexpr int W = CAP::kWaves;  // waves per workgroup; two workgroups per CU (LDS)
   int64_t grid = (p.n_obs + W - 1) / W;
-  if (grid > 256 * 2 * 8) grid = 256 * 2 * 8;
-  hipLaunchKernelGGL((wave_loo_chunked_kernel<T, VEC, CapsBig>), dim3((unsigned)grid), dim3(kWave * W), 0, stream, p, f);
+  if (grid > 2048 * 8 / W) grid = 2048 * 8 / W;
+  hipLaunchKernelGGL((wave_loo_chunked_kernel<T, VEC, CAP>), dim3((unsigned)grid), dim3(kWave * W), 0, stream, p, f);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   constexpr int BLOCK = 256;
@@ -316,9 +316,12 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream) {
           p.n_draws >= 256 && p.n_draws <= (1 << 20) && last_chunk >= kWave * WVEC && p.tail_count <= CapsBig::kMaxTail &&
           smem_bytes(BLOCK, p.tail_cap) <= 64 * 1024 && p.n_obs <= 0xffffffffll) {
         int gsz = 0, kq = 0;
-        if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, CapsBig::kCand)) {
-          return launch_chunked<T, WVEC>(p, gsz, kq, stream);
-        }
+        if (p.tail_count <= CapsMid4::kMaxTail && wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, CapsMid4::kCand))
+          return launch_chunked<T, WVEC, CapsMid4>(p, gsz, kq, stream);
+        if (p.tail_count <= CapsMid::kMaxTail && wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, CapsMid::kCand))
+          return launch_chunked<T, WVEC, CapsMid>(p, gsz, kq, stream);
+        if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, CapsBig::kCand))
+          return launch_chunked<T, WVEC, CapsBig>(p, gsz, kq, stream);
       }
     }
     if (path == 1) return launch_one<T, BLOCK, 0, LW>(p, stream);

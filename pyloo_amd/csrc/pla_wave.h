@@ -70,6 +70,18 @@ struct CapsBig {                                    // long rows in chunks / sma
   static constexpr int kMaxTail = 512;
   static constexpr int kWaves = 2;
 };
+struct CapsMid {                                    // chunked rows with M <= 448 (S = 20 000, reff = 1): 6 waves per CU
+  static constexpr int kCand = 1536;
+  static constexpr int kSa = 640;
+  static constexpr int kMaxTail = 448;
+  static constexpr int kWaves = 3;
+};
+struct CapsMid4 {                                   // M <= 320 (S up to ~11 000 at reff = 1, or reff >= 0.35 at S = 4000): 8 waves per CU
+  static constexpr int kCand = 1088;
+  static constexpr int kSa = 512;
+  static constexpr int kMaxTail = 320;
+  static constexpr int kWaves = 4;
+};
 constexpr int kCandCap = CapsSmall::kCand;
 constexpr int kWaveCap = CapsSmall::kSa;
 constexpr int kWaveMaxTail = CapsSmall::kMaxTail;
