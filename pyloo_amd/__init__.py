@@ -5,10 +5,11 @@ through the C ABI in ``include/pyloo_amd.h``; there is no CPU fallback."""
 from .base import ISMethod, compute_importance_weights
 from .elpd import ELPDData
 from .loo import loo, loo_from_matrix
+from .loo_i import loo_i
 from .psis import psislw
 from .rcparams import rcParams
 from .waic import waic, waic_from_matrix
 
-__all__ = ["ISMethod", "ELPDData", "compute_importance_weights", "loo", "loo_from_matrix", "psislw", "rcParams", "waic",
+__all__ = ["ISMethod", "ELPDData", "compute_importance_weights", "loo", "loo_from_matrix", "loo_i", "psislw", "rcParams", "waic",
            "waic_from_matrix"]
 __version__ = "0.1.0"

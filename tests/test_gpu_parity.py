@@ -506,3 +506,24 @@ def test_device_path_is_graph_capturable(eng):
     for key in ("diag", "loo_i", "lppd_i", "agg"):
         assert torch.equal(out[key], fresh[key]), key
     assert not torch.equal(out["loo_i"], warm["loo_i"])
+
+
+def test_loo_i_front(eng):
+    """loo_i (loo_i.py:16-294) through the real engine: the one row's weights come from the GPU."""
+    import pyloo_amd as pl
+
+    rng = np.random.default_rng(9)
+    ll = -0.45 * rng.exponential(size=(6, 4000)) - 2.0
+    d = {"log_likelihood": {"obs": np.moveaxis(ll.reshape(6, 4, 1000), 0, -1)}, "posterior": {"mu": np.zeros((4, 1000))}}
+    res = pl.loo_i(4, d, reff=0.9, pointwise=True)
+    lw, diag = orc.importance_weights(-ll[4][None, :], "psis", 0.9)
+    lwll = lw + ll[4][None, :]
+    want = orc.lse(lwll[0])
+    np.testing.assert_allclose(res["elpd_loo"], want, rtol=RTOL)
+    np.testing.assert_allclose(np.asarray(res["pareto_k"]).ravel(), diag, rtol=RTOL)
+    w = np.exp(lwll - lwll.max())
+    w /= w.sum()
+    se = np.sqrt(np.log1p(np.sum(w**2 * (np.exp(ll[4]) - np.exp(want)) ** 2) / 0.9 / np.exp(want) ** 2))
+    np.testing.assert_allclose(res["se"], se, rtol=1e-8)
+    full = pl.loo(d, reff=0.9, pointwise=True)
+    np.testing.assert_allclose(np.asarray(full["loo_i"]).ravel()[4], want, rtol=RTOL)

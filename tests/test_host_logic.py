@@ -213,3 +213,50 @@ def test_rcparams():
     finally:
         pl.rcParams["stats.ic_scale"] = "log"
     assert list(pl.rcParams) == sorted(pl.rcParams.keys())
+
+
+def _loo_i_reference(ll_row, reff, scale_value=1, method="psis"):
+    """loo_i.py:183-239 restated with the oracle (weights of one row, SE from the weights)."""
+    S = ll_row.shape[0]
+    lw, diag = orc.importance_weights(-ll_row[None, :], method, reff)
+    lwll = lw + ll_row[None, :]
+    loo = scale_value * orc.lse(lwll[0])
+    w = np.exp(lwll - lwll.max(axis=-1, keepdims=True))
+    w /= w.sum(axis=-1, keepdims=True)
+    e_epd = np.exp(loo)
+    var = np.sum(w**2 * (np.exp(ll_row[None, :]) - e_epd) ** 2) / reff
+    se = np.sqrt(np.log1p(var / e_epd**2))
+    lppd = orc.lse(ll_row, b_inv=S)
+    return loo, se, lppd - loo / scale_value, diag
+
+
+def test_loo_i(ll8, monkeypatch):  # test_loo_i.py of the reference: layout, values, errors
+    import importlib
+
+    monkeypatch.setattr(importlib.import_module("pyloo_amd.base"), "get_engine", lambda device=None: OracleEngine())
+    d = idata(ll8)
+    res = pl.loo_i(3, d, reff=0.8)
+    assert list(res.index) == ["elpd_loo", "se", "p_loo", "n_samples", "n_data_points", "warning", "scale", "good_k"]  # loo_i.py:242-258
+    loo, se, p_loo, diag = _loo_i_reference(ll8[3], 0.8)
+    np.testing.assert_allclose(res["elpd_loo"], loo, rtol=1e-12)
+    np.testing.assert_allclose(res["se"], se, rtol=1e-10)
+    np.testing.assert_allclose(res["p_loo"], p_loo, rtol=1e-10)
+    assert res["n_data_points"] == 1 and res["n_samples"] == 2000
+    pw = pl.loo_i(3, d, reff=0.8, pointwise=True, scale="deviance")
+    assert list(pw.index) == ["elpd_loo", "se", "p_loo", "n_samples", "n_data_points", "warning", "loo_i", "scale",
+                              "pareto_k", "good_k"]  # loo_i.py:260-292
+    np.testing.assert_allclose(pw["elpd_loo"], -2 * loo, rtol=1e-12)
+    np.testing.assert_allclose(np.asarray(pw["pareto_k"]).ravel(), diag, rtol=1e-12)
+    with pytest.warns(UserWarning, match="Using SIS"):
+        sis = pl.loo_i(0, d, reff=1.0, method="sis", pointwise=True)
+    assert "ess" in sis.index and "good_k" not in sis.index
+    with pytest.raises(ValueError, match="single integer"):
+        pl.loo_i([0, 1], d, reff=1.0)
+    with pytest.raises(TypeError, match="must be an integer"):
+        pl.loo_i("a", d, reff=1.0)
+    with pytest.raises(IndexError, match="out of bounds"):
+        pl.loo_i(8, d, reff=1.0)
+    with pytest.raises(ValueError, match="Invalid method"):
+        pl.loo_i(0, d, reff=1.0, method="nope")
+    with pytest.raises(TypeError, match="Valid scale values"):
+        pl.loo_i(0, d, reff=1.0, scale="nope")
