@@ -527,3 +527,21 @@ def test_loo_i_front(eng):
     np.testing.assert_allclose(res["se"], se, rtol=1e-8)
     full = pl.loo(d, reff=0.9, pointwise=True)
     np.testing.assert_allclose(np.asarray(full["loo_i"]).ravel()[4], want, rtol=RTOL)
+
+
+def test_observation_fastest_device_layout(eng):
+    """(S, N) buffer viewed as (N, S) -- the ArviZ-native layout: transposed on the device, then the fast path."""
+    import torch
+
+    rng = np.random.default_rng(21)
+    ll = -0.5 * rng.exponential(size=(500, 4000)) - 1.0
+    ref = orc.loo_arrays(ll, 1.0)
+    buf = torch.from_numpy(np.ascontiguousarray(ll.T)).cuda()   # (S, N), observations fastest
+    view = buf.T
+    assert view.stride(1) != 1
+    res = eng.psis_loo(view, 190, "psis", 1.0, 0.7)
+    close(res["diag"].cpu().numpy(), ref["khat"], what="khat")
+    close(res["loo_i"].cpu().numpy(), ref["loo_i"], what="loo_i")
+    assert int(res["agg"][7].item()) == 0                       # the wave kernel took every row
+    lw, k = eng.importance_weights(-view, 190, "psis")
+    close(lw.cpu().numpy(), ref["lw"], what="lw")
