@@ -545,3 +545,22 @@ def test_observation_fastest_device_layout(eng):
     assert int(res["agg"][7].item()) == 0                       # the wave kernel took every row
     lw, k = eng.importance_weights(-view, 190, "psis")
     close(lw.cpu().numpy(), ref["lw"], what="lw")
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 5, 63, 65])
+@pytest.mark.parametrize("S,dt", [(256, np.float64), (258, np.float64), (1000, np.float32), (4094, np.float64),
+                                  (4096, np.float64), (4096, np.float32), (4100, np.float64), (8192, np.float32)])
+def test_odd_shapes(eng, N, S, dt):
+    """Row counts that do not fill a workgroup and draw counts at the edges of the register chunk."""
+    rng = np.random.default_rng(N * 10007 + S)
+    ll = (-rng.uniform(0.1, 0.9, size=(N, 1)) * rng.exponential(size=(N, S)) - 0.5).astype(dt)
+    ref = orc.loo_arrays(ll.astype(np.float64), 1.0)
+    M = orc.tail_count(S, 1.0)
+    res = eng.psis_loo(ll, M, "psis", 1.0, ref["good_k"])
+    close(res["diag"], ref["khat"], what="khat")
+    close(res["loo_i"], ref["loo_i"], what="loo_i")
+    close(res["lppd_i"], ref["lppd_i"], what="lppd_i")
+    np.testing.assert_allclose(res["agg"][1], ref["elpd_loo"], rtol=RTOL)
+    w = eng.waic(ll, 1.0)
+    wr = orc.waic_arrays(ll.astype(np.float64), 1)
+    np.testing.assert_allclose(w["waic_i"], wr["waic_i"], rtol=1e-10, atol=1e-10)
