@@ -93,8 +93,9 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
       mn = -(double)vmx;
       gs = (double)snap;
     }
-    const double mc = wave_all<R_MAX>(mx);
-    const double mnc = wave_all<R_MIN>(mn);
+    double mc, nmnc;
+    wave_all2<R_MAX>(mx, -mn, mc, nmnc);  // min = -max(-.)
+    const double mnc = -nmnc;
     m_run = fmax(m_run, mc);
     mn_run = fmin(mn_run, mnc);
     if (ch == 0) {

@@ -59,8 +59,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void is_wave_kernel(Rows
       mx = (double)cur;
       mn = -(double)vmx;
     }
-    const double m = wave_all<R_MAX>(mx);
-    mn = wave_all<R_MIN>(mn);
+    double m, nmn;
+    wave_all2<R_MAX>(mx, -mn, m, nmn);  // min = -max(-.)
+    mn = -nmn;
     const double R = m - mn;
     bool slow = !(R < kWaveMaxRange);  // also inf / NaN through the maximum or the minimum
     double ess = 0.0, loo = 0.0, lppd = 0.0;
@@ -92,8 +93,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void is_wave_kernel(Rows
       sb = fma(-ncopy, b0, sb);
       sc = fma(-ncopy, c0, sc);
     }
-    double A = wave_all<R_SUM>(sa), B = 0.0, D = (double)S;
-    const double C = wave_all<R_SUM>(sc);
+    double A, C, B = 0.0, D = (double)S;
+    wave_all2<R_SUM>(sa, sc, A, C);
     if constexpr (!tis) {
       B = wave_all<R_SUM>(sb);
     } else {
@@ -122,8 +123,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void is_wave_kernel(Rows
 #pragma unroll
       for (int e = 0; e < VEC; ++e) term(first[e] - m2, a0, b0, d0);
       A = wave_all<R_SUM>(fma(-ncopy, a0, ta));
-      B = wave_all<R_SUM>(fma(-ncopy, b0, tb));
-      D = wave_all<R_SUM>(fma(-ncopy, d0, td));
+      wave_all2<R_SUM>(fma(-ncopy, b0, tb), fma(-ncopy, d0, td), B, D);
     }
     ess = div_fast(A * A, B);
     const double lg = log_tab(lane == 1 ? C : (lane == 2 ? D : A), lt);

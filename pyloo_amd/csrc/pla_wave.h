@@ -169,6 +169,23 @@ __device__ __forceinline__ double wave_all(double v) {
   return lane_value(v, 63);
 }
 
+// Two wave-wide reductions for the price of one and a bit: v_permlane32_swap (gfx950) leaves the pairwise
+// combination of `a` across the two half-waves in lanes 0-31 and that of `b` in lanes 32-63; four DPP steps
+// reduce inside the rows and one row_bcast:15 joins rows 0+1 (-> lane 31 = a) and rows 2+3 (-> lane 63 = b).
+template <RedOp OP>
+__device__ __forceinline__ void wave_all2(double a, double b, double& ra, double& rb) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+  double v = red2<OP>(__hiloint2double(hi[0], lo[0]), __hiloint2double(hi[1], lo[1]));
+  v = red2<OP>(v, dpp_mov_u<0xB1, 0xF>(v));   // quad_perm [1,0,3,2]
+  v = red2<OP>(v, dpp_mov_u<0x4E, 0xF>(v));   // quad_perm [2,3,0,1]
+  v = red2<OP>(v, dpp_mov_u<0x141, 0xF>(v));  // row_half_mirror
+  v = red2<OP>(v, dpp_mov_u<0x140, 0xF>(v));  // row_mirror
+  v = red2<OP>(v, dpp_mov_u<0x142, 0xA>(v));  // row_bcast:15 into rows 1 and 3
+  ra = lane_value(v, 31);
+  rb = lane_value(v, 63);
+}
+
 template <class CAP>
 struct WaveSmemT {
   using Caps = CAP;
@@ -550,8 +567,8 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
       const double se = wave_all<R_SUM>(w);
       w = anynan ? qnan() : w * recip_fast(se);
       const bool keep = act && (w >= 10.0 * kEps);                                // psis.py:194-197
-      const double sw = wave_all<R_SUM>(keep ? w : 0.0);
-      const double bw = wave_all<R_SUM>(keep ? b * w : 0.0);
+      double sw, bw;
+      wave_all2<R_SUM>(keep ? w : 0.0, keep ? b * w : 0.0, sw, bw);
       const double b_post = (sw > 0.0) ? div_fast(bw, sw) : 0.0;                  // psis.py:198,201
       // psis.py:203: mean_i log1p(-b_post*y_i) as the log of per-lane products
       PLA_PHASE(12);
@@ -636,8 +653,9 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
     // The tail's exponentials are subtracted from a sum that contains them (acc_t = sum w' - sum e): when
     // the smoothed tail is far lighter than the raw one (a draw tens of nats above the rest) that
     // cancels catastrophically, and such rows are left to the general kernel, which sums like the reference.
-    const double s1_all = wave_all<R_SUM>(s1);
-    const double total = smoothed ? s1_all + wave_all<R_SUM>(acc_t) : s1_all;
+    double s1_all, at_all;
+    wave_all2<R_SUM>(s1, acc_t, s1_all, at_all);  // (acc_t is 0 in every lane when nothing was smoothed)
+    const double total = s1_all + at_all;
     if (!(total > 0.01 * s1_all)) slow = true;
     if constexpr (LW) {
       // ---- weights mode: lw_s = x_s - log(total) for every draw, the smoothed tail at its positions ----
@@ -678,10 +696,11 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
         }
       }
     } else {
-      s2 = wave_all<R_SUM>(s2);
+      double ar_all;
+      wave_all2<R_SUM>(s2, acc_r, s2, ar_all);
       // loo_i = -m - L + log(tail_ratio),  L = log(total) (psis.py:158; loo.py:289,319-324): one log
       double tail_ratio = (double)S;
-      if (smoothed) tail_ratio = (double)(S - n) + wave_all<R_SUM>(acc_r);
+      if (smoothed) tail_ratio = (double)(S - n) + ar_all;
       // the two logs of the row in one call: lane 1 takes s2, every other lane the weight ratio
       const double lg = log_tab(lane == 1 ? s2 : div_fast(tail_ratio, total), tb.lt);
       loo = lane_value(lg, 0) - m;
@@ -748,8 +767,9 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     mn = LW ? (double)vmx : -(double)vmx;
     gs = (double)snap;
   }
-  const double m = wave_all<R_MAX>(mx);
-  mn = wave_all<R_MIN>(mn);
+  double m, nmn;
+  wave_all2<R_MAX>(mx, -mn, m, nmn);  // min = -max(-.)
+  mn = -nmn;
   const double R = m - mn;
   // Speculative candidate threshold: a value with at least `kq` of the 64 per-lane group maxima
   // below it, found by bisection on ballots.  For exchangeable draws a fraction ~(kq/64)^(1/gsz) of
