@@ -186,6 +186,30 @@ __device__ __forceinline__ void wave_all2(double a, double b, double& ra, double
   rb = lane_value(v, 63);
 }
 
+// Four at once: after the half-wave swap of (a, b) and (c, d), v_permlane16_swap interleaves the rows so that
+// each 16-lane row holds the partial results of ONE quantity; four DPP steps inside the rows finish the job
+// (row 0 = a, row 1 = c, row 2 = b, row 3 = d).  21 + 8 instructions for four reductions.
+template <RedOp OP>
+__device__ __forceinline__ void wave_all4(double a, double b, double c, double d, double& ra, double& rb, double& rc, double& rd) {
+  const auto l1 = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+  const auto h1 = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+  const double ab = red2<OP>(__hiloint2double(h1[0], l1[0]), __hiloint2double(h1[1], l1[1]));  // rows 0,1: a; rows 2,3: b
+  const auto l2 = __builtin_amdgcn_permlane32_swap(__double2loint(c), __double2loint(d), false, false);
+  const auto h2 = __builtin_amdgcn_permlane32_swap(__double2hiint(c), __double2hiint(d), false, false);
+  const double cd = red2<OP>(__hiloint2double(h2[0], l2[0]), __hiloint2double(h2[1], l2[1]));  // rows 0,1: c; rows 2,3: d
+  const auto l3 = __builtin_amdgcn_permlane16_swap(__double2loint(ab), __double2loint(cd), false, false);
+  const auto h3 = __builtin_amdgcn_permlane16_swap(__double2hiint(ab), __double2hiint(cd), false, false);
+  double v = red2<OP>(__hiloint2double(h3[0], l3[0]), __hiloint2double(h3[1], l3[1]));  // rows: a, c, b, d
+  v = red2<OP>(v, dpp_mov_u<0xB1, 0xF>(v));
+  v = red2<OP>(v, dpp_mov_u<0x4E, 0xF>(v));
+  v = red2<OP>(v, dpp_mov_u<0x141, 0xF>(v));
+  v = red2<OP>(v, dpp_mov_u<0x140, 0xF>(v));
+  ra = lane_value(v, 0);
+  rc = lane_value(v, 16);
+  rb = lane_value(v, 32);
+  rd = lane_value(v, 48);
+}
+
 template <class CAP>
 struct WaveSmemT {
   using Caps = CAP;
@@ -653,8 +677,9 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
     // The tail's exponentials are subtracted from a sum that contains them (acc_t = sum w' - sum e): when
     // the smoothed tail is far lighter than the raw one (a draw tens of nats above the rest) that
     // cancels catastrophically, and such rows are left to the general kernel, which sums like the reference.
-    double s1_all, at_all;
-    wave_all2<R_SUM>(s1, acc_t, s1_all, at_all);  // (acc_t is 0 in every lane when nothing was smoothed)
+    double s1_all, at_all, s2_all = 0.0, ar_all = 0.0;
+    if constexpr (LW) wave_all2<R_SUM>(s1, acc_t, s1_all, at_all);  // (acc_t is 0 in every lane when nothing was smoothed)
+    else wave_all4<R_SUM>(s1, acc_t, s2, acc_r, s1_all, at_all, s2_all, ar_all);
     const double total = s1_all + at_all;
     if (!(total > 0.01 * s1_all)) slow = true;
     if constexpr (LW) {
@@ -696,8 +721,7 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
         }
       }
     } else {
-      double ar_all;
-      wave_all2<R_SUM>(s2, acc_r, s2, ar_all);
+      s2 = s2_all;
       // loo_i = -m - L + log(tail_ratio),  L = log(total) (psis.py:158; loo.py:289,319-324): one log
       double tail_ratio = (double)S;
       if (smoothed) tail_ratio = (double)(S - n) + ar_all;
@@ -767,8 +791,8 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     mn = LW ? (double)vmx : -(double)vmx;
     gs = (double)snap;
   }
-  double m, nmn;
-  wave_all2<R_MAX>(mx, -mn, m, nmn);  // min = -max(-.)
+  double m, nmn, ngs, unused_;
+  wave_all4<R_MAX>(mx, -mn, -gs, -gs, m, nmn, ngs, unused_);  // min = -max(-.): row max, row min, smallest group maximum
   mn = -nmn;
   const double R = m - mn;
   // Speculative candidate threshold: a value with at least `kq` of the 64 per-lane group maxima
@@ -777,7 +801,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   // this is ~3(M+1)); rows where the guess is off are recomputed by the general kernel.
   double t1;
   {
-    double lo = wave_all<R_MIN>(gs), hi = m;
+    double lo = -ngs, hi = m;
 #pragma unroll 1
     for (int it = 0; it < PLA_BISECT_ITERS; ++it) {  // 2^-iters of the spread of the group maxima: a handful of candidates
       const double mid = 0.5 * (lo + hi);
