@@ -516,15 +516,23 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
       wave_sync();
       const double* y = sm.sa;
       const double nn = (double)n;
-      // (1 - b y0)(1 - b y1) = 1 - b (y0 + y1) + b^2 y0 y1: pair sums / products once per row
+      // prod_{i<4} (1 - b y_i) = 1 - e1 b + e2 b^2 - e3 b^3 + e4 b^4: the elementary symmetric sums of every
+      // four consecutive y, once per row (4 fma + 1 mul per grid point and quad instead of 2 x 3 for pairs)
       {
-        constexpr int PU = kBigTail ? 4 : 2;  // pairs per lane
-        double2 yy[PU];
+        constexpr int QU = kBigTail ? 2 : 1;  // quads per lane
+        double2 ya[QU], yb[QU];
 #pragma unroll
-        for (int u = 0; u < PU; ++u) yy[u] = *reinterpret_cast<const double2*>(y + 2 * (lane + kWave * u));
+        for (int u = 0; u < QU; ++u) {
+          ya[u] = *reinterpret_cast<const double2*>(y + 4 * (lane + kWave * u));
+          yb[u] = *reinterpret_cast<const double2*>(y + 4 * (lane + kWave * u) + 2);
+        }
 #pragma unroll
-        for (int u = 0; u < PU; ++u)
-          *reinterpret_cast<double2*>(&sb[2 * (lane + kWave * u)]) = make_double2(yy[u].x + yy[u].y, yy[u].x * yy[u].y);
+        for (int u = 0; u < QU; ++u) {
+          const double s01 = ya[u].x + ya[u].y, p01 = ya[u].x * ya[u].y, s23 = yb[u].x + yb[u].y, p23 = yb[u].x * yb[u].y;
+          double* o = &sb[4 * (lane + kWave * u)];
+          *reinterpret_cast<double2*>(o) = make_double2(s01 + s23, fma(s01, s23, p01 + p23));
+          *reinterpret_cast<double2*>(o + 2) = make_double2(fma(p01, s23, p23 * s01), p01 * p23);
+        }
       }
       wave_sync();
       const double* yp = sb;
@@ -552,15 +560,17 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
       double corr = 0.0;
       int i = 0;
       if (wide && !tiny) {
-        // factors within 2^+-15: four trips (8 pair factors per accumulator each) fit between renorms
+        // factors within 2^+-15: four trips (4 quad factors per accumulator each) fit between renorms
         const bool narrow = (fbig < 0x1p15) && (fsmall > 0x1p-15);
         for (; i < n32; i += 32) {
 #pragma unroll
-          for (int u = 0; u < 32; u += 4) {
-            const double2 pa = *reinterpret_cast<const double2*>(yp + i + u);
-            const double2 pb = *reinterpret_cast<const double2*>(yp + i + u + 2);
-            acc.mul(fma(nb, fma(nb, pa.y, pa.x), 1.0));
-            acc2.mul(fma(nb, fma(nb, pb.y, pb.x), 1.0));
+          for (int u = 0; u < 32; u += 8) {
+            const double2 a12 = *reinterpret_cast<const double2*>(yp + i + u);      // e1, e2 of one quad
+            const double2 a34 = *reinterpret_cast<const double2*>(yp + i + u + 2);  // e3, e4
+            const double2 b12 = *reinterpret_cast<const double2*>(yp + i + u + 4);  // the next quad
+            const double2 b34 = *reinterpret_cast<const double2*>(yp + i + u + 6);
+            acc.mul(fma(nb, fma(nb, fma(nb, fma(nb, a34.y, a34.x), a12.y), a12.x), 1.0));
+            acc2.mul(fma(nb, fma(nb, fma(nb, fma(nb, b34.y, b34.x), b12.y), b12.x), 1.0));
           }
           if (!narrow || (i & 96) == 96) {
             acc.renorm();
