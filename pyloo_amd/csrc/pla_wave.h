@@ -811,14 +811,18 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   // this is ~3(M+1)); rows where the guess is off are recomputed by the general kernel.
   double t1;
   {
-    double lo = -ngs, hi = m;
+    // bisection in fixed point: the group maxima as integers in [0, 2^20] (one VALU compare per step, the
+    // interval lives in scalar registers)
+    const double lo0 = -ngs, spread = m - lo0;
+    const int ki = (int)((gs - lo0) * (1048576.0 * recip_fast(spread)));  // spread = 0 (constant sample): t1 = 0 -> general kernel
+    int lo_i = 0, hi_i = 1 << 20;
 #pragma unroll 1
     for (int it = 0; it < PLA_BISECT_ITERS; ++it) {  // 2^-iters of the spread of the group maxima: a handful of candidates
-      const double mid = 0.5 * (lo + hi);
-      const int below = __popcll(__ballot(gs < mid));
-      if (below >= kq) hi = mid; else lo = mid;
+      const int mid = (lo_i + hi_i) >> 1;
+      const int below = __popcll(__ballot(ki < mid));
+      if (below >= kq) hi_i = mid; else lo_i = mid;
     }
-    t1 = hi - m;
+    t1 = fma((double)hi_i, spread * (1.0 / 1048576.0), lo0) - m;
   }
   // +-inf in the row makes R inf/NaN; a NaN draw is ignored by v_max here, poisons s1 in the sweep
   // and is caught by the finiteness test at the end: both land on the general kernel
