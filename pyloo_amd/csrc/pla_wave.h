@@ -599,8 +599,9 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
       const bool anynan = (__ballot(act && (ls != ls)) != 0ull) || !(fabs(lmax) < INF);
       double w = act ? exp_neg(ls - lmax, tb.tab) : 0.0;                          // psis.py:192
       const double se = wave_all<R_SUM>(w);
-      w = anynan ? qnan() : w * recip_fast(se);
-      const bool keep = act && (w >= 10.0 * kEps);                                // psis.py:194-197
+      // the weights stay unnormalised (b_post is a ratio): w/se >= 10 eps  <=>  w >= 10 eps se
+      if (anynan) w = qnan();
+      const bool keep = act && (w >= (10.0 * kEps) * se);                         // psis.py:194-197
       double sw, bw;
       wave_all2<R_SUM>(keep ? w : 0.0, keep ? b * w : 0.0, sw, bw);
       const double b_post = (sw > 0.0) ? div_fast(bw, sw) : 0.0;                  // psis.py:198,201
