@@ -115,6 +115,32 @@ def _diagnostic_warning(method, agg, good_k, n_samples):
     return False
 
 
+def _replace_nan(values):
+    """loo.py:218-227 / loo_i.py:155-164: NaN log-likelihoods count as -1e10, with a warning."""
+    nan_mask = np.isnan(values)
+    if not nan_mask.any():
+        return values
+    warnings.warn(
+        "NaN values detected in log-likelihood. These will be ignored in the LOO calculation.",
+        UserWarning,
+        stacklevel=3,
+    )
+    return np.where(nan_mask, values.dtype.type(-1e10), values)
+
+
+def _checked_method(method):
+    """loo.py:229-244 / loo_i.py:166-181: parse the method, recommend PSIS when something else is asked for."""
+    method = parse_method(method)
+    if method != ISMethod.PSIS:
+        warnings.warn(
+            f"Using {method.value.upper()} for LOO computation. Note that PSIS is the"
+            " recommended method as it is typically more efficient and reliable.",
+            UserWarning,
+            stacklevel=3,
+        )
+    return method
+
+
 def _pack(summ, n_samples, n_data_points, warn, scale, method, good_k, pointwise, loo_i=None, diag=None):
     """Index order of loo.py:516-626 + 360-365 / 400-410."""
     data = [summ["elpd_loo"], summ["se"], summ["p_loo"], summ["p_loo_se"], n_samples, n_data_points, warn]
@@ -177,22 +203,8 @@ def loo(data, pointwise=None, var_name=None, reff=None, scale=None, method="psis
     scale, scale_value = _scale_value(scale)
     if reff is None:
         reff = _relative_efficiency(idata, n_samples)
-    nan_mask = np.isnan(matrix)
-    if nan_mask.any():  # loo.py:218-227
-        warnings.warn(
-            "NaN values detected in log-likelihood. These will be ignored in the LOO calculation.",
-            UserWarning,
-            stacklevel=2,
-        )
-        matrix = np.where(nan_mask, matrix.dtype.type(-1e10), matrix)
-    method = parse_method(method)
-    if method != ISMethod.PSIS:  # loo.py:235-244
-        warnings.warn(
-            f"Using {method.value.upper()} for LOO computation. Note that PSIS is the"
-            " recommended method as it is typically more efficient and reliable.",
-            UserWarning,
-            stacklevel=2,
-        )
+    matrix = _replace_nan(matrix)  # loo.py:218-227
+    method = _checked_method(method)  # loo.py:229-244
     good_k = min(1 - 1 / np.log10(n_samples), 0.7)  # loo.py:249
     if mixture:
         raise NotImplementedError("mixture=True (Mix-IS-LOO, loo.py:252-284) is outside the scope of pyloo_amd")

@@ -4,13 +4,12 @@ HIP engine (``compute_importance_weights`` -> ``pla_importance_weights``); the s
 pointwise value needs the weights themselves (loo_i.py:221-230), which is why this front uses the
 weights-returning entry point rather than the fused LOO pass."""
 
-import warnings
-
 import numpy as np
 
-from .base import ISMethod, compute_importance_weights, parse_method
+from ._capi import AGG_COUNT, AGG_MIN_DIAG, AGG_N_HIGH
+from .base import ISMethod, compute_importance_weights
 from .elpd import ELPDData
-from .loo import _relative_efficiency, _scale_value
+from .loo import _checked_method, _diagnostic_warning, _relative_efficiency, _replace_nan, _scale_value
 from .rcparams import rcParams
 from .utils import get_log_likelihood, stack_samples, to_inference_data, wrap_obs
 
@@ -45,51 +44,18 @@ def loo_i(i, data, pointwise=None, var_name=None, reff=None, scale=None, method=
     scale, scale_value = _scale_value(scale)
     if reff is None:
         reff = _relative_efficiency(idata, n_samples)
-    if np.isnan(ll_i).any():  # loo_i.py:155-164
-        warnings.warn(
-            "NaN values detected in log-likelihood. These will be ignored in the LOO calculation.",
-            UserWarning,
-            stacklevel=2,
-        )
-        ll_i = np.where(np.isnan(ll_i), -1e10, ll_i)
-    method = parse_method(method)
-    if method != ISMethod.PSIS:  # loo_i.py:172-181
-        warnings.warn(
-            f"Using {method.value.upper()} for LOO computation. Note that PSIS is the"
-            " recommended method as it is typically more efficient and reliable.",
-            UserWarning,
-            stacklevel=2,
-        )
+    ll_i = _replace_nan(ll_i)          # loo_i.py:155-164
+    method = _checked_method(method)   # loo_i.py:166-181
 
     lw, diagnostic = compute_importance_weights(-ll_i[None, :], method=method, reff=reff)  # loo_i.py:183-185
     log_weights = np.asarray(lw, dtype=np.float64) + ll_i[None, :]                         # loo_i.py:186
     diagnostic = np.asarray(diagnostic, dtype=np.float64)
 
-    warn_mg = False
     good_k = min(1 - 1 / np.log10(n_samples), 0.7)
-    if method == ISMethod.PSIS:
-        if np.any(diagnostic > good_k):
-            n_high_k = int(np.sum(diagnostic > good_k))
-            warnings.warn(
-                "Estimated shape parameter of Pareto distribution is greater than"
-                f" {good_k:.2f} for {n_high_k} observations. This indicates that"
-                " importance sampling may be unreliable because the marginal"
-                " posterior and LOO posterior are very different.",
-                UserWarning,
-                stacklevel=2,
-            )
-            warn_mg = True
-    else:
-        min_ess = float(np.min(diagnostic))
-        if min_ess < n_samples * 0.1:
-            warnings.warn(
-                f"Low effective sample size detected (minimum ESS: {min_ess:.1f}). This"
-                " indicates that the importance sampling approximation may be"
-                " unreliable. Consider using PSIS which is more robust to such cases.",
-                UserWarning,
-                stacklevel=2,
-            )
-            warn_mg = True
+    agg = np.zeros(AGG_COUNT)  # the diagnostic summary the shared warning helper reads (loo_i.py:191-212)
+    agg[AGG_N_HIGH] = np.sum(diagnostic > good_k)
+    agg[AGG_MIN_DIAG] = np.min(diagnostic)
+    warn_mg = _diagnostic_warning(method, agg, good_k, n_samples)
 
     with np.errstate(all="ignore"):
         loo_lppd_i = scale_value * np.array([_lse(log_weights[0])])  # loo_i.py:214-217

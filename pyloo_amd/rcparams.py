@@ -52,20 +52,17 @@ class RcParams(MutableMapping):
     def __getitem__(self, key):
         return self._store[key]
 
-    def __delitem__(self, key):
-        raise TypeError("RcParams keys cannot be deleted")
+    # the mapping is frozen: every way of removing or implicitly adding a key raises (rcparams.py:75-105)
+    def _frozen(msg):  # noqa: N805 - helper evaluated in the class body
+        def method(self, *args, **kwargs):
+            raise TypeError(msg)
 
-    def clear(self):
-        raise TypeError("RcParams keys cannot be deleted")
+        return method
 
-    def pop(self, key, default=None):
-        raise TypeError("RcParams keys cannot be deleted. Use .get(key) or RcParams[key] to check values")
-
-    def popitem(self):
-        raise TypeError("RcParams keys cannot be deleted. Use .get(key) or RcParams[key] to check values")
-
-    def setdefault(self, key, default=None):
-        raise TypeError("Defaults in RcParams are handled on object initialization. Use pyloo configuration file instead.")
+    __delitem__ = clear = _frozen("RcParams keys cannot be deleted")
+    pop = popitem = _frozen("RcParams keys cannot be deleted. Use .get(key) or RcParams[key] to check values")
+    setdefault = _frozen("Defaults in RcParams are handled on object initialization. Use pyloo configuration file instead.")
+    del _frozen
 
     def __iter__(self):
         return iter(sorted(self._store))
