@@ -1,29 +1,34 @@
-// Wave-per-observation LOO kernel (the production fast path for S <= 4096 draws).
+// Wave-per-observation LOO kernel (the production fast path for S <= 4096 draws, tail counts <= 250).
 //
-// One 64-lane wavefront owns one observation: the row of S draws sits in its registers
-// (64 slots per lane, loaded once with 16-byte loads), and every later step is done by that
-// wave alone with DPP cross-lane reductions and a private LDS scratch -- there is NO workgroup
-// barrier anywhere, so the 8 waves resident on a CU run their phases (HBM load, exp sweep,
-// selection, GPD fit) completely decoupled and cover each other's latencies.
+// One 64-lane wavefront owns one observation: the row of S draws sits in its registers (64 slots per
+// lane, loaded once with 16-byte buffer loads), and every later step is done by that wave alone with
+// DPP / permlane cross-lane reductions and a private LDS scratch.  Workgroups hold 4 such waves that only
+// share read-only tables; there is NO workgroup barrier in the row loop, so the 8 waves resident on a CU
+// run their phases (HBM load, exp sweep, selection, GPD fit) completely decoupled.
 //
-//   stats     max / min / non-finite test / min over groups of the group maxima (threshold t1:
-//             at least #groups >= M+1 draws lie at or above it)
-//   sweep     for every draw ONE range reduction x = k*ln2/256 + r gives both e^x and
-//             e^(ll - max ll) = e^(-x-R): a 256-entry LDS table of {2^(j/256), 2^(-j/256) e^-R},
-//             a degree-4 even/odd polynomial and an integer add to the exponent field.
-//             The integer k doubles as the histogram key: draws with k >= k(t1) are counted in
-//             up to 1024 linear bins of width 2^sh * ln2/256.
-//   select    suffix scan -> boundary bin of rank M; draws at/above it are scattered to LDS
-//             grouped by bin and ranked exactly inside their bin
-//   fit       Zhang-Stephens GPD fit, one lane per grid point b_j, log(prod) instead of sum(log1p)
-//   smooth    GPD quantiles, sums of the smoothed weights; loo_i / lppd_i from the sums
+//   stats     max / min of the row and the smallest of the per-lane maxima over the first `gsz` slots
+//             (one four-way reduction); a fixed-point bisection on ballots puts the speculative candidate
+//             threshold t1 where ~2.2 (M+1) draws lie above it
+//   sweep     for every draw ONE range reduction x = k*ln2/256 + r gives both e^x and e^-x: a 256-entry
+//             LDS table of biased {2^(j/256), 2^(-j/256)} pairs, an even/odd polynomial and an integer
+//             multiply-add into the exponent field.  Draws with x >= t1 are appended to an LDS list
+//             (ballot + mbcnt rank, scalar running offset).  Behind the sweep the NEXT row's vectors
+//             stream into the registers it has consumed.
+//   select    512-bin histogram of the list over the integer keys k, DPP prefix scan -> boundary bin of
+//             rank M; candidates at/above it are scattered to LDS grouped by bin and ranked exactly
+//             inside their bin (4-wide batched LDS reads)
+//   fit       Zhang-Stephens GPD fit, one lane per grid point b_j, log(prod(1 - b_j y_i)) over quads of
+//             tail values (elementary symmetric sums) instead of m_est x n log1p; table-driven log
+//   smooth    GPD quantiles from host tables, sums of the smoothed weights; loo_i / lppd_i from the sums
 //
-// Slots beyond S are padded so that no per-slot predicate is needed: first with a copy of the
-// lane's own first draws (harmless for max/min), then with ll = -min raw (x = -R, the smallest
-// x of the row), whose exactly known contribution is subtracted from the two sums.
+// Slots beyond S are padded so that no per-slot predicate is needed: first with a copy of the lane's own
+// first draws (harmless for max / min), then with ll = -min raw (x = -R, the smallest x of the row),
+// whose exactly known contribution is subtracted from the two sums.
 //
-// Rows the shortcuts cannot reproduce exactly as the reference computes them are appended to a
-// list and recomputed by the general kernel (pla_rows.h).
+// Rows the shortcuts cannot reproduce as the reference computes them (non-finite entries, more than 690
+// nats of range, a threshold miss, a tail that cancels against the sum of all exponentials) are appended
+// to a device list and recomputed by the general kernel (pla_rows.h).  Weights mode (LW = true) writes
+// the normalised smoothed log-weights instead of loo_i / lppd_i.
 #pragma once
 
 #include <type_traits>
