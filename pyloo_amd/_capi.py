@@ -6,8 +6,6 @@ import os
 
 import numpy as np
 
-from .build import LIB_PATH
-
 PLA_F64, PLA_F32 = 0, 1
 PLA_HOST, PLA_DEVICE = 0, 1
 PLA_PSIS, PLA_SIS, PLA_TIS = 0, 1, 2
@@ -40,6 +38,8 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    from .build import LIB_PATH  # (imported here so that `python -m pyloo_amd.build` runs the module once)
+
     lib_path = os.environ.get("PYLOO_AMD_LIB", LIB_PATH)  # profiling builds (tools/ablate.sh)
     if not os.path.exists(lib_path):
         raise RuntimeError(
