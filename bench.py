@@ -206,6 +206,15 @@ def main():
                       f"restating pyloo utils.py:171-175 + psis.py:114-160 + loo.py:289-337), {t_cpu:.1f} s",
         }
         out["parity"] = {"rows": done, "max_rel_err": worst, "tolerance": 1e-6}
+        # second, clearly labelled CPU line: whole-matrix NumPy calls instead of the loop
+        vrows = min(2048, cap)
+        host = ll[:vrows].cpu().numpy().astype(np.float64)
+        c0 = time.perf_counter()
+        orc.loo_pointwise_vectorised(host, reff)
+        out["cpu_baseline_vectorised"] = {
+            "value": vrows / (time.perf_counter() - c0), "unit": "obs/s", "cores": 1, "kind": "port",
+            "sample": f"first {vrows} observations, batched NumPy restatement (not the reference's loop structure)",
+        }
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -118,3 +118,19 @@ def test_unit_primitives():
             lw, ess = f(r)
             _close(lw, u[f"{nm}_lw"][j])
             _close(ess, u[f"{nm}_ess"][j])
+
+
+def test_vectorised_backend_equals_the_loop():
+    """oracle.loo_pointwise_vectorised (second CPU line of the bench) against the per-observation loop."""
+    rng = np.random.default_rng(8)
+    ll = -rng.uniform(0.05, 1.3, size=(96, 1)) * rng.exponential(size=(96, 2000)) - 1.0
+    ll[3, 7] = np.nan
+    ll[5] = -2.0
+    ll[9, :300] = np.round(ll[9, :300] * 4) / 4
+    ll[11, 0] = -np.inf
+    a = orc.loo_pointwise(ll, 0.8)
+    b = orc.loo_pointwise_vectorised(ll, 0.8, chunk=32)
+    for key in ("diag", "loo_i", "lppd_i"):
+        assert np.array_equal(np.isnan(a[key]), np.isnan(b[key])), key
+        ok = np.isfinite(a[key])
+        np.testing.assert_allclose(b[key][ok], a[key][ok], rtol=1e-12, atol=1e-13)
