@@ -814,7 +814,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   // Speculative candidate threshold: a value with at least `kq` of the 64 per-lane group maxima
   // below it, found by bisection on ballots.  For exchangeable draws a fraction ~(kq/64)^(1/gsz) of
   // the row lies below it, i.e. a few hundred draws lie above (the launcher picks gsz and kq so that
-  // this is ~3(M+1)); rows where the guess is off are recomputed by the general kernel.
+  // this is ~2.2(M+1)); rows where the guess is off are recomputed by the general kernel.
   double t1;
   {
     // bisection in fixed point: the group maxima as integers in [0, 2^20] (one VALU compare per step, the
