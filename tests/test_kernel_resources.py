@@ -1,0 +1,40 @@
+"""Static guard on the generated gfx950 code of the hot kernels (no GPU needed: hipcc cross-compiles).
+
+Two failure modes cost hours in round 1 and are invisible in the source: scratch spills (they turn a
+register-resident row into HBM traffic) and SGPR spills to VGPR lanes (``v_writelane``), which next to scratch
+spills produced wrong results on this toolchain.  The row kernels must have neither, must keep two waves
+per SIMD, and their LDS must allow two workgroups per CU."""
+
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+KERNELS = {
+    "wave_loo_kernelIdLi2ELb0ENS_9CapsSmall": 81920,   # LOO, f64
+    "wave_loo_kernelIfLi4ELb0ENS_9CapsSmall": 81920,   # LOO, f32
+    "wave_loo_kernelIdLi2ELb1ENS_9CapsSmall": 81920,   # weights mode
+    "wave_loo_chunked_kernelIdLi2ENS_8CapsMid4": 81920,
+    "wave_loo_chunked_kernelIfLi4ENS_7CapsMid": 81920,
+    "waic_wave_kernelIdLi2": 81920,
+    "is_wave_kernelIdLi2ELb0": 81920,
+    "is_wave_kernelIdLi2ELb1": 81920,
+}
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+def test_row_kernels_do_not_spill(tmp_path):
+    import isa_stats
+
+    lines = isa_stats.compile_isa(out=str(tmp_path / "kernels.s"))
+    for pat, lds_limit in KERNELS.items():
+        name, total, _, res = isa_stats.kernel_stats(lines, pat)
+        assert res.get("ScratchSize", 0) == 0, (name, res)
+        assert total.get("v_writelane_b32", 0) == 0, (name, dict(total))
+        assert not any(k.startswith("scratch_") for k in total), (name, dict(total))
+        assert res.get("NumVgprs", 0) <= 256 and res.get("Occupancy", 0) >= 1, (name, res)
+        assert res.get("LDSByteSize", 0) <= lds_limit, (name, res)  # two workgroups per CU (160 KB LDS)

@@ -15,14 +15,16 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main():
-    pat = sys.argv[1] if len(sys.argv) > 1 else "wave_loo_kernelIdLi2"
-    extra = sys.argv[2:]
-    out = "/tmp/pla_isa.s"
+def compile_isa(extra=(), out="/tmp/pla_isa.s"):
+    """One device-only compile of pla_kernels.hip to gfx950 assembly; returns the lines."""
     cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-disable-machine-licm",
-           "--offload-device-only", "-S", "-o", out, os.path.join(ROOT, "pyloo_amd/csrc/pla_kernels.hip")] + extra
+           "--offload-device-only", "-S", "-o", out, os.path.join(ROOT, "pyloo_amd/csrc/pla_kernels.hip")] + list(extra)
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
-    lines = open(out).read().split("\n")
+    return open(out).read().split("\n")
+
+
+def kernel_stats(lines, pat):
+    """Instruction mix, per-phase mix and resource lines of the first kernel whose mangled name contains `pat`."""
     start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + re.escape(pat) + r"\w*:", l))
     end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
     total = collections.Counter()
@@ -44,15 +46,25 @@ def main():
                 c[op] += 1
             if op.startswith("s_cbranch") or op == "s_branch":
                 c["branch"] += 1
-    print(lines[start].split(":")[0])
+    res = {}
+    for l in lines[end:end + 80]:
+        m = re.search(r"; (NumVgprs|NumAgprs|ScratchSize|Occupancy|LDSByteSize|NumSgprs): (\d+)", l)
+        if m:
+            res[m.group(1)] = int(m.group(2))
+    return lines[start].split(":")[0], total, phases, res
+
+
+def main():
+    pat = sys.argv[1] if len(sys.argv) > 1 else "wave_loo_kernelIdLi2"
+    lines = compile_isa(sys.argv[2:])
+    name, total, phases, res = kernel_stats(lines, pat)
+    print(name)
     print(" total", dict(total))
     if len(phases) > 1:
         for k in sorted(phases):
             print(f"  phase {k:2d}", dict(phases[k]))
-    for l in lines[end:end + 80]:
-        if re.search(r"\.(vgpr_count|sgpr_count|private_segment_fixed_size|sgpr_spill_count|vgpr_spill_count)", l) or \
-           re.search(r"; (NumVgprs|NumAgprs|ScratchSize|Occupancy|LDSByteSize|SGPRSpill|NumSgprs)", l):
-            print(" ", l.strip())
+    for k, v in res.items():
+        print(f"  ; {k}: {v}")
 
 
 if __name__ == "__main__":
