@@ -283,7 +283,9 @@ __device__ __forceinline__ unsigned byte0_shl(int k, int sh) {
 // VEC*(lane + 64 q) + e).  The row is the bounds-checked range of the buffer descriptor: one VGPR
 // offset (lane*16), scalar per-q offsets, zeros past the end.  Nothing waits here: the loads stay
 // in flight until the slots are first used.
-template <typename T, int VEC>
+// AUX: cache policy of the loads (2 = non-temporal: the row is read once; 0 = default: weights mode reads
+// the row a second time and wants it to stay in L2 / the Infinity Cache)
+template <typename T, int VEC, int AUX = 2>
 __device__ __forceinline__ void issue_row_loads(T (&v)[kWaveSlots], const T* rp, int S) {
   constexpr int NQ = kWaveSlots / VEC;
   typedef int v4i __attribute__((ext_vector_type(4)));
@@ -292,7 +294,7 @@ __device__ __forceinline__ void issue_row_loads(T (&v)[kWaveSlots], const T* rp,
       __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(rp), 0, S * (int)sizeof(T), 0x00020000);
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const v4i t = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, q * (kWave * 16), 2 /* nt */);
+    const v4i t = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, q * (kWave * 16), AUX);
     if constexpr (VEC == 2) {
       v[2 * q] = (T)__hiloint2double(t[1], t[0]);
       v[2 * q + 1] = (T)__hiloint2double(t[3], t[2]);
@@ -719,7 +721,7 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
 #pragma unroll
               for (int e = 0; e < 4; ++e) t[e] = __float_as_int((float)(((double)v[4 * q + e] - m) - L));
             }
-            __builtin_amdgcn_raw_buffer_store_b128(t, ro, lane * 16, q * (kWave * 16), 0);
+            __builtin_amdgcn_raw_buffer_store_b128(t, ro, lane * 16, q * (kWave * 16), 0);  // (non-temporal stores measured 5 % slower)
             // gfx9 hazard: a VALU write to the data registers of a > 8-byte buffer store with an SGPR offset
             // needs a wait state after the store.  The compiler's hazard pass misses it across the block
             // boundary that follows the last store (observed: the low dword of the stored value replaced
@@ -976,7 +978,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   // the next row starts streaming into the (now dead) row registers while the outputs are stored and
   // the other wave of this SIMD computes
   PLA_PHASE(15);
-  if (!streamed && rp_next) issue_row_loads<T, VEC>(v, rp_next, S);  // rows that never reached the sweep
+  if (!streamed && rp_next) issue_row_loads<T, VEC, LW ? 0 : 2>(v, rp_next, S);  // rows that never reached the sweep (weights mode: every row)
   if (lane == 0) {
     if (slow) {
       const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
@@ -1012,7 +1014,7 @@ __global__ __launch_bounds__(kWave * CAP::kWaves, PLA_MIN_WAVES_PER_SIMD) void w
   T v[kWaveSlots];
   const T* base = reinterpret_cast<const T*>(P.in);
   const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + wv, nw = (int64_t)gridDim.x * kWavesPerBlock;
-  if (w0 < P.n_obs) issue_row_loads<T, VEC>(v, base + w0 * P.stride_obs, P.n_draws);
+  if (w0 < P.n_obs) issue_row_loads<T, VEC, LW ? 0 : 2>(v, base + w0 * P.stride_obs, P.n_draws);
 #if PLA_WAVE_ABLATE
   unsigned long long ck0, rt0;
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck0), "=s"(rt0));
