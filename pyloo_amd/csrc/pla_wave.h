@@ -51,6 +51,9 @@ namespace pla {
 #ifndef PLA_WAVES_PER_BLOCK
 #define PLA_WAVES_PER_BLOCK 4
 #endif
+#ifndef PLA_LOAD_AUX
+#define PLA_LOAD_AUX 2  // cache policy of the single-read row loads: 2 = non-temporal
+#endif
 #ifndef PLA_BISECT_ITERS
 #define PLA_BISECT_ITERS 9
 #endif
@@ -309,7 +312,7 @@ __device__ __forceinline__ void issue_row_loads(T (&v)[kWaveSlots], const T* rp,
 template <typename T, int VEC>
 __device__ __forceinline__ void issue_row_vector(T (&v)[kWaveSlots], const __amdgpu_buffer_rsrc_t rs, int q) {
   typedef int v4i __attribute__((ext_vector_type(4)));
-  const v4i t = __builtin_amdgcn_raw_buffer_load_b128(rs, wave_lane() * 16, q * (kWave * 16), 2 /* nt */);
+  const v4i t = __builtin_amdgcn_raw_buffer_load_b128(rs, wave_lane() * 16, q * (kWave * 16), PLA_LOAD_AUX);
   if constexpr (VEC == 2) {
     v[2 * q] = (T)__hiloint2double(t[1], t[0]);
     v[2 * q + 1] = (T)__hiloint2double(t[3], t[2]);
@@ -978,7 +981,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   // the next row starts streaming into the (now dead) row registers while the outputs are stored and
   // the other wave of this SIMD computes
   PLA_PHASE(15);
-  if (!streamed && rp_next) issue_row_loads<T, VEC, LW ? 0 : 2>(v, rp_next, S);  // rows that never reached the sweep (weights mode: every row)
+  if (!streamed && rp_next) issue_row_loads<T, VEC, LW ? 0 : PLA_LOAD_AUX>(v, rp_next, S);  // rows that never reached the sweep (weights mode: every row)
   if (lane == 0) {
     if (slow) {
       const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
@@ -1014,7 +1017,7 @@ __global__ __launch_bounds__(kWave * CAP::kWaves, PLA_MIN_WAVES_PER_SIMD) void w
   T v[kWaveSlots];
   const T* base = reinterpret_cast<const T*>(P.in);
   const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + wv, nw = (int64_t)gridDim.x * kWavesPerBlock;
-  if (w0 < P.n_obs) issue_row_loads<T, VEC, LW ? 0 : 2>(v, base + w0 * P.stride_obs, P.n_draws);
+  if (w0 < P.n_obs) issue_row_loads<T, VEC, LW ? 0 : PLA_LOAD_AUX>(v, base + w0 * P.stride_obs, P.n_draws);
 #if PLA_WAVE_ABLATE
   unsigned long long ck0, rt0;
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck0), "=s"(rt0));
