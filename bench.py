@@ -79,16 +79,23 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal knobs (a one-GPU box cannot run RCCL with two ranks): PYLOO_AMD_BENCH_BACKEND=gloo and
+    # PYLOO_AMD_BENCH_DEVICE=0 put every rank on one card and reduce over gloo; the driver's runs use neither.
+    backend = os.environ.get("PYLOO_AMD_BENCH_BACKEND", "nccl")
+    dev_index = int(os.environ.get("PYLOO_AMD_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from pyloo_amd.base import tail_count_for
     from pyloo_amd.engine import get_engine
     from pyloo_amd.sharded import all_reduce_aggregates
 
-    eng = get_engine(local_rank)
+    eng = get_engine(dev_index)
     S, n_local = args.draws, args.obs
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
     esz = 8 if args.dtype == "f64" else 4
@@ -126,7 +133,7 @@ def main():
     k_ms, k_n = eng.kernel_ms()
     eng.set_timing(False)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     agg = agg.cpu().numpy() if hasattr(agg, "cpu") else np.asarray(agg)

@@ -63,7 +63,9 @@ def all_reduce_aggregates(agg, group=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     t = agg if hasattr(agg, "detach") else torch.as_tensor(np.asarray(agg), dtype=torch.float64)
-    table = torch.zeros((world, AGG_COUNT), dtype=torch.float64, device=t.device)
-    table[rank] = t.to(torch.float64)
+    # RCCL reduces device tensors in place; gloo (CPU tests, rehearsals) wants host tensors
+    where = t.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    table = torch.zeros((world, AGG_COUNT), dtype=torch.float64, device=where)
+    table[rank] = t.to(device=where, dtype=torch.float64)
     dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)  # the single collective
     return merge_moment_rows(table.cpu().numpy())
