@@ -54,6 +54,8 @@ struct pla_engine {
   void* d_slow = nullptr;  // [n] row list of the fast path
   size_t d_slow_bytes = 0;
   double* d_l1 = nullptr;  // log1p(-(j+0.5)/M), j < M, for the current tail count
+  void* d_ws = nullptr;    // hand-over buffers of the split LOO pass: [n][stride] tail values + [n][8] scalars
+  size_t d_ws_bytes = 0;
   size_t d_l1_bytes = 0;
   int64_t l1_M = -1;
   // timing of the main kernel
@@ -205,6 +207,7 @@ int pla_engine_destroy(pla_engine* e) {
   if (e->d_pw) (void)hipFree(e->d_pw);
   if (e->d_slow) (void)hipFree(e->d_slow);
   if (e->d_l1) (void)hipFree(e->d_l1);
+  if (e->d_ws) (void)hipFree(e->d_ws);
   for (int i = 0; i < pla_engine::kTimingRing; ++i) {
     if (e->ev0[i]) (void)hipEventDestroy(e->ev0[i]);
     if (e->ev1[i]) (void)hipEventDestroy(e->ev1[i]);
@@ -296,6 +299,18 @@ int pla_psis_loo(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int6
       rc = ensure_l1_table(eng, tail_count, s);
       if (rc) return rc;
       p.l1_table = eng->d_l1;
+      // hand-over buffers of the split pass (one-chunk wave kernel -> fit kernel, pla_fit.h): sized for the
+      // rows one launch processes (all of them on the device path, one staging chunk on the host path)
+      if (tail_count <= 250 && n_draws <= 4096) {
+        const int64_t chunk_rows = (int64_t)(((size_t)1 << 30) / ((size_t)n_draws * esz));
+        const int64_t rows = mem_space == PLA_DEVICE ? n_obs : (chunk_rows < 1 ? 1 : (chunk_rows < n_obs ? chunk_rows : n_obs));
+        const int stride = (int)((tail_count + 63) & ~(int64_t)63);  // 16 lanes x 4 values per quad
+        rc = grow(&eng->d_ws, &eng->d_ws_bytes, (size_t)rows * (size_t)(stride + 8) * sizeof(double));
+        if (rc) return rc;
+        p.ws_y = (double*)eng->d_ws;
+        p.ws_s = (double*)eng->d_ws + (size_t)rows * stride;
+        p.ws_stride = stride;
+      }
     }
   }
 

@@ -23,6 +23,10 @@ struct FastParams {
   double log_S;                   // log(n_draws)
   const double* b_grid;           // [64] 1 - sqrt(m_est/(j+0.5)) for m_est = mest_M (psis.py:186)
   int mest_M;                     // 30 + isqrt(M)
+  // split pass (pla_fit.h): hand-over buffers of the wave kernel, null when the pass is fused
+  double* ws_y = nullptr;         // [n_obs][ws_stride] ascending tail values
+  double* ws_s = nullptr;         // [n_obs][8] scalars
+  int ws_stride = 0;
 };
 
 }  // namespace pla

@@ -1,0 +1,263 @@
+// Sixteen-lanes-per-observation GPD fit, smoothing sums and outputs: the second half of the split LOO pass.
+//
+// The wave kernel (pla_wave.h) is wave-per-observation because a row of S draws needs the whole register
+// file; but everything after the exact selection works on <= 256 tail values per observation, and there a
+// wavefront per observation wastes most of its lanes (21 of 64 in the grid, 63 of 64 in every scalar step,
+// six-step cross-lane reductions everywhere).  In the split pass the wave kernel stops after the selection
+// and hands over, per observation, the ascending tail values y_j (psis.py:146-147) and six scalars; this
+// kernel gives every DPP row of 16 lanes one observation (four observations per wavefront):
+//   * the tail sits in the registers of its 16 lanes (4 NQ values each, one coalesced read);
+//   * the Zhang-Stephens grid (psis.py:163-208) is three grid points b_j per lane; the factors
+//     prod_i (1 - b_j y_i) are taken four y at a time as a quartic in the grid coordinate whose five
+//     coefficients each lane builds for its own quads and every lane of the row reads back from LDS
+//     (same-address reads: a broadcast);
+//   * reductions are four DPP steps inside the row, never across rows.
+// Same arithmetic as wave_back(): mantissa / exponent accumulators instead of sums of log1p, table-driven
+// exp / log, loo_i from the algebraic shortcut.  Observations with a grid point whose |b_j y_n| < 2^-14 (the
+// product would lose the digits of b_j y), an unusual m_est, factors beyond 2^+-30, sigma <= 0, a tiny khat,
+// a cancelling total or a non-finite result are appended to the device list for the general kernel, like
+// the observations the wave kernel declined.
+#pragma once
+
+#include "pla_wave.h"
+
+namespace pla {
+
+constexpr int kFitWaves = 4;       // waves per workgroup (they share the tables)
+constexpr int kFitGrid = 48;       // three grid points per lane: m_est = 30 + isqrt(n) <= 46 for n <= 256
+constexpr int kFitCoefStride = 6;  // doubles per quad in LDS (five used): 48 bytes keep the 16-byte alignment
+
+struct FitParams {
+  const double* ws_y;   // [n_obs][ws_stride] ascending tail values, zero padded; ws_stride = 64 NQ
+  const double* ws_s;   // [n_obs][8]: max raw, min raw, sum_all e^x, sum_all e^-x, e^xcut, n (-1: declined), -, -
+  int ws_stride;
+  int64_t n_obs;
+  int n_draws;
+  int tail_count;
+  int mest_M;
+  double log_S;
+  double scale_value;
+  const double* l1_table;  // [M] log1p(-(j+0.5)/M)
+  const double* b_grid;    // [64] 1 - sqrt(m_est/(j+0.5)) for m_est = mest_M
+  double* diag;
+  double* loo_i;
+  double* lppd_i;
+  unsigned* slow_list;
+  unsigned long long* counters;
+};
+
+// reduction over the 16 lanes of a DPP row; every lane of the row ends up with the (bitwise identical) result
+template <class F>
+__device__ __forceinline__ double row_all(double v, F op) {
+  v = op(v, dpp_mov_u<0xB1, 0xF>(v));   // quad_perm [1,0,3,2]
+  v = op(v, dpp_mov_u<0x4E, 0xF>(v));   // quad_perm [2,3,0,1]
+  v = op(v, dpp_mov_u<0x141, 0xF>(v));  // row_half_mirror
+  v = op(v, dpp_mov_u<0x140, 0xF>(v));  // row_mirror
+  return v;
+}
+__device__ __forceinline__ int row_all_add(int v) {
+  v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, false);
+  v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, false);
+  v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, false);
+  v += __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, false);
+  return v;
+}
+
+template <int NQ>
+__global__ __launch_bounds__(kWave * kFitWaves) void fit_rows_kernel(FitParams Q) {
+  __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];
+  __shared__ __attribute__((aligned(16))) double lt[2 * kLogTabN];
+  __shared__ __attribute__((aligned(16))) double l1s[64 * NQ];
+  __shared__ __attribute__((aligned(16))) double coef[kFitWaves * 4 * 16 * NQ * kFitCoefStride];
+  const int tid = threadIdx.x;
+  const int M = Q.tail_count, S = Q.n_draws, mestM = Q.mest_M;
+  for (int j = tid; j < kTabN; j += kWave * kFitWaves) exp_table_entry(tab, j);
+  for (int j = tid; j < kLogTabN; j += kWave * kFitWaves) log_table_entry(lt, j);
+  for (int j = tid; j < 64 * NQ; j += kWave * kFitWaves) l1s[j] = Q.l1_table[j < M ? j : M - 1];
+  __syncthreads();
+  const double INF = pinf();
+  const auto op_sum = [](double a, double b) { return a + b; };
+  const auto op_mul = [](double a, double b) { return a * b; };
+  const auto op_max = [](double a, double b) { return vmax_nc<false>(a, b); };
+  const int lane = wave_lane(), t = lane & 15, rho = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+  double* cf_row = coef + (size_t)((wv * 4 + rho) * 16 * NQ) * kFitCoefStride;
+  // grid coordinates of this lane: j = t, t + 16, t + 32
+  double g[3];
+  bool gact[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int j = t + 16 * c;
+    gact[c] = j < mestM;
+    g[c] = Q.b_grid[gact[c] ? j : 0];
+  }
+  const double g_first = Q.b_grid[0], g_last = Q.b_grid[mestM - 1];
+  const int64_t ngroups = (Q.n_obs + 3) >> 2;
+  for (int64_t grp = (int64_t)blockIdx.x * kFitWaves + wv; grp < ngroups; grp += (int64_t)gridDim.x * kFitWaves) {
+    const int64_t r0 = grp * 4 + rho;
+    const bool inrange = r0 < Q.n_obs;
+    const int64_t r = inrange ? r0 : Q.n_obs - 1;
+    const double* sc = Q.ws_s + r * 8;
+    const double2 sc01 = *reinterpret_cast<const double2*>(sc), sc23 = *reinterpret_cast<const double2*>(sc + 2),
+                  sc45 = *reinterpret_cast<const double2*>(sc + 4);
+    const double m = sc01.x, mn = sc01.y, s1 = sc23.x, s2 = sc23.y, e_cut = sc45.x;
+    const int nraw = (int)sc45.y;
+    const bool handled = inrange && nraw >= 0;  // (else: past the end, or declined by the wave kernel and already listed)
+    const int n = nraw < 0 ? 0 : (nraw > M ? M : nraw);
+    const bool fit = n > 4;  // psis.py:139: shorter tails are neither fitted nor smoothed (their y was not written)
+    const double* y = Q.ws_y + r * (int64_t)Q.ws_stride;
+    double2 yv[2 * NQ];  // element j = 32 i + 2 t + {0, 1}
+#pragma unroll
+    for (int i = 0; i < 2 * NQ; ++i) yv[i] = *reinterpret_cast<const double2*>(y + 32 * i + 2 * t);
+    const int iq = ((n + 2) >> 2) - 1;
+    const double yq = y[iq > 0 ? iq : 0], yn = y[n > 0 ? n - 1 : 0];
+    const double R = m - mn;
+    const double nn = (double)n, rn = recip_fast(nn);
+    bool bad = (30 + isqrt_i(n)) != mestM;  // (ties shortened the tail a lot: the host grid table does not apply)
+    // b_j = g_j / (3 yq) + 1 / yn (psis.py:186-188), kept as the two per-observation scalars
+    const double cb = recip_fast(3.0 * yq), db = recip_fast(yn);
+    {
+      const double fbig = fma(-fma(g_first, cb, db), yn, 1.0), fsmall = fma(-fma(g_last, cb, db), yn, 1.0);
+      if (!((fbig < 0x1p30) && (fsmall > 0x1p-30))) bad = true;
+    }
+    // ---- quartic coefficients of this lane's quads --------------------------------------------------------
+    // 1 - b_j y = (1 - y/yn) - g_j y/(3 yq) = u + g_j t with u >= 0, t <= 0 and every g_j < 0: the product over
+    // four y is a quartic in g_j whose terms are all non-negative (no cancellation)
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const double y0 = yv[2 * k].x, y1 = yv[2 * k].y, y2 = yv[2 * k + 1].x, y3 = yv[2 * k + 1].y;
+      const double u0 = fma(-db, y0, 1.0), u1 = fma(-db, y1, 1.0), u2 = fma(-db, y2, 1.0), u3 = fma(-db, y3, 1.0);
+      const double t0 = -cb * y0, t1 = -cb * y1, t2 = -cb * y2, t3 = -cb * y3;
+      const double A0 = u0 * u1, A1 = fma(u0, t1, u1 * t0), A2 = t0 * t1;
+      const double B0 = u2 * u3, B1 = fma(u2, t3, u3 * t2), B2 = t2 * t3;
+      double* o = cf_row + (k * 16 + t) * kFitCoefStride;
+      *reinterpret_cast<double2*>(o) = make_double2(A0 * B0, fma(A0, B1, A1 * B0));
+      *reinterpret_cast<double2*>(o + 2) = make_double2(fma(A0, B2, fma(A1, B1, A2 * B0)), fma(A1, B2, A2 * B1));
+      o[4] = A2 * B2;
+    }
+    wave_sync();
+    // ---- grid pass: three running products per lane over the 16 NQ quads of the observation -------------------
+    double pm[3] = {1.0, 1.0, 1.0};
+    int pe[3] = {0, 0, 0};
+#pragma unroll 1
+    for (int q8 = 0; q8 < 16 * NQ; q8 += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const double* cq = cf_row + (q8 + u) * kFitCoefStride;
+        const double2 c01 = *reinterpret_cast<const double2*>(cq), c23 = *reinterpret_cast<const double2*>(cq + 2);
+        const double c4 = cq[4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pm[c] *= fma(g[c], fma(g[c], fma(g[c], fma(g[c], c4, c23.y), c23.x), c01.y), c01.x);
+      }
+      // factors within 2^+-120 per quad: eight fit between renormalisations
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        pe[c] += __builtin_amdgcn_frexp_exp(pm[c]);
+        pm[c] = __builtin_amdgcn_frexp_mant(pm[c]);
+      }
+    }
+    wave_sync();  // (the next group's coefficients are written after these reads)
+    // ---- profile likelihood, softmax weights, posterior mean of b (psis.py:190-201) --------------------------
+    double ls[3], bb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double b = fma(g[c], cb, db);
+      bb[c] = b;
+      if (gact[c] && fabs(b * yn) < 0x1p-14) bad = true;  // 1 - b y would round away the digits of b y
+      const double kj = (log_tab(pm[c], lt) + (double)pe[c] * kLn2) * rn;                         // psis.py:190
+      const double l = nn * (log_tab(gact[c] ? -div_fast(b, kj) : 1.0, lt) - kj - 1.0);           // psis.py:191
+      if (gact[c] && l != l) bad = true;  // NaN anywhere: every weight is NaN in the reference; the general kernel does that
+      ls[c] = gact[c] ? l : -INF;
+    }
+    const double lmax = row_all(vmax_nc<false>(vmax_nc<false>(ls[0], ls[1]), ls[2]), op_max);
+    if (!(fabs(lmax) < INF)) bad = true;
+    double w[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) w[c] = gact[c] ? exp_neg(ls[c] - lmax, tab) : 0.0;                // psis.py:192
+    const double se = row_all((w[0] + w[1]) + w[2], op_sum);
+    // the weights stay unnormalised (b_post is a ratio): w/se >= 10 eps  <=>  w >= 10 eps se   (psis.py:194-197)
+    double swl = 0.0, bwl = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const bool keep = w[c] >= (10.0 * kEps) * se;
+      swl += keep ? w[c] : 0.0;
+      bwl += keep ? bb[c] * w[c] : 0.0;
+    }
+    const double sw = row_all(swl, op_sum), bw = row_all(bwl, op_sum);
+    const double b_post = (sw > 0.0) ? div_fast(bw, sw) : 0.0;                                    // psis.py:198,201
+    // ---- k_post = mean log1p(-b_post y) (psis.py:203) from the lane's own quads --------------------------------
+    double km = 1.0;
+    {
+      const double nb = -b_post;
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) {
+        const double y0 = yv[2 * k].x, y1 = yv[2 * k].y, y2 = yv[2 * k + 1].x, y3 = yv[2 * k + 1].y;
+        const double s01 = y0 + y1, p01 = y0 * y1, s23 = y2 + y3, p23 = y2 * y3;
+        const double e1 = s01 + s23, e2 = fma(s01, s23, p01 + p23), e3 = fma(p01, s23, p23 * s01), e4 = p01 * p23;
+        km *= fma(nb, fma(nb, fma(nb, fma(nb, e4, e3), e2), e1), 1.0);
+      }
+    }
+    const int ke = row_all_add(__builtin_amdgcn_frexp_exp(km));
+    const double kmr = row_all(__builtin_amdgcn_frexp_mant(km), op_mul);  // >= 2^-16
+    const double k_post = (log_tab(kmr, lt) + (double)ke * kLn2) * rn;
+    const double sigma = -k_post / b_post;                                                        // psis.py:205
+    const double khat = (nn * k_post + 5.0) / (nn + 10.0);                                        // psis.py:206
+    // ---- smoothed tail: sums of w'_j - e_j and w'_j / e_j (psis.py:150-158, 211-231) ---------------------------
+    const bool smoothed = fit && isfinite(khat);
+    // w_j = sigma/k (e^{z_j} - 1) + e_cut with z_j = -k log1p(-p_j); e^z - 1 by subtraction is accurate to 1e-16
+    // ABSOLUTE, which is all the sum w_j + e_cut can see.  sigma <= 0 (NaN quantiles, psis.py:214-215) and
+    // |k| < eps (psis.py:218) are left to the general kernel.
+    if (smoothed && (!(sigma > 0.0) || fabs(khat) < kEps)) bad = true;
+    const double coef_s = sigma / khat, off = e_cut - coef_s;
+    double acc_t = 0.0, acc_r = 0.0;
+    const auto smooth = [&](int j, double l1, double yj) {
+      const double ez = exp_tab(fmin(-khat * l1, 700.0), tab);
+      const double wj = fmin(fma(ez, coef_s, off), 1.0);  // exp(log(q + e_cut)) clipped at 0 (psis.py:155,157)
+      const double ej = yj + e_cut;
+      acc_t += (j < n) ? wj - ej : 0.0;
+      acc_r += (j < n) ? div_fast(wj, ej) : 0.0;
+      asm volatile("" : "+v"(acc_t), "+v"(acc_r));  // one element at a time: the scheduler would start them all and spill
+    };
+    if (__ballot(fit && n != M) == 0ull) {
+      // the usual case, straight-line: log1p(-p_j) from the host table (psis.py:153)
+#pragma unroll
+      for (int i = 0; i < 2 * NQ; ++i) {
+        const int j = 32 * i + 2 * t;
+        const double2 l1 = *reinterpret_cast<const double2*>(l1s + j);
+        smooth(j, l1.x, yv[i].x);
+        smooth(j + 1, l1.y, yv[i].y);
+      }
+    } else {
+      // ties shortened some tail of this wave: p_j = (j + 0.5)/n with the observation's own n
+#pragma unroll 1
+      for (int i = 0; i < 4 * NQ; ++i) {
+        const int j = 16 * i + t;
+        smooth(j, n == M ? l1s[j] : log_fast(1.0 - ((double)j + 0.5) * rn), y[j]);
+      }
+    }
+    const double at = row_all(acc_t, op_sum), ar = row_all(acc_r, op_sum);
+    // ---- outputs (loo.py:289,319-337 through the shortcuts of DESIGN.md section 4) --------------------------
+    const double total = smoothed ? s1 + at : s1;
+    bool bad_out = !(total > 0.01 * s1);  // the tail cancels against the sum of all exponentials
+    const double tail_ratio = smoothed ? (double)(S - n) + ar : (double)S;
+    const double lg = log_tab(t == 1 ? s2 : div_fast(tail_ratio, total), lt);
+    const double lg1 = dpp_mov_u<0xB1, 0xF>(lg);  // lane t = 0 receives lane 1's logarithm
+    const double loo = lg - m;
+    const double lppd = (lg1 - R) + ((-mn) - Q.log_S);
+    if (!(total > 1e-280) || !isfinite(loo) || !isfinite(lppd)) bad_out = true;
+    const unsigned long long badm = __ballot(bad);
+    const bool slow = (fit && ((badm >> (lane & 48)) & 0xFFFFull) != 0ull) || bad_out;
+    if (handled && t == 0) {
+      if (slow) {
+        const unsigned long long idx = atomicAdd(&Q.counters[0], 1ull);
+        Q.slow_list[idx] = (unsigned)r;
+      } else {
+        if (Q.diag) Q.diag[r] = fit ? khat : INF;
+        if (Q.loo_i) Q.loo_i[r] = Q.scale_value * loo;
+        if (Q.lppd_i) Q.lppd_i[r] = lppd;
+      }
+    }
+  }
+}
+
+}  // namespace pla

@@ -21,6 +21,7 @@
 #include "pla_waic.h"
 #include "pla_chunked.h"
 #include "pla_is.h"
+#include "pla_fit.h"
 
 namespace pla {
 
@@ -226,6 +227,7 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, hipStream_t 
   hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   static const int dbg = debug_flag("PLA_DEBUG_SKIP");
+  static const int fused = debug_flag("PLA_FUSED");  // 1: single fused kernel (the pre-split pass), for A/B runs
   int root_ = (int)std::sqrt((double)p.tail_count);
   while (root_ * root_ > p.tail_count) --root_;
   while ((root_ + 1) * (root_ + 1) <= p.tail_count) ++root_;
@@ -235,9 +237,39 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, hipStream_t 
   // 256 CUs (8 waves each) busy with a short tail
   int64_t grid = (p.n_obs + kWavesPerBlock - 1) / kWavesPerBlock;
   if (grid > 2048 * 8 / kWavesPerBlock) grid = 2048 * 8 / kWavesPerBlock;
-  hipLaunchKernelGGL((wave_loo_kernel<T, VEC, LW, CapsSmall>), dim3((unsigned)grid), dim3(kWave * kWavesPerBlock), 0, stream, p, f);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
+  const bool split = !LW && !fused && !dbg && p.ws_y && p.ws_s && mestM <= kFitGrid && p.ws_stride % 64 == 0 && p.ws_stride <= 256 &&
+                     p.tail_count <= p.ws_stride;
+  if constexpr (!LW) {
+    if (split) {
+      // split pass: wave kernel up to the exact selection, then sixteen lanes per observation for the GPD fit,
+      // the smoothing sums and the outputs (pla_fit.h)
+      f.ws_y = p.ws_y;
+      f.ws_s = p.ws_s;
+      f.ws_stride = p.ws_stride;
+      hipLaunchKernelGGL((wave_loo_kernel<T, VEC, false, CapsSmall, true>), dim3((unsigned)grid), dim3(kWave * kWavesPerBlock), 0,
+                         stream, p, f);
+      e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      FitParams q{p.ws_y, p.ws_s, p.ws_stride, p.n_obs, p.n_draws, p.tail_count, mestM, f.log_S, p.scale_value, p.l1_table,
+                  p.l1_table + p.tail_count, p.diag, p.loo_i, p.lppd_i, p.slow_list, p.counters};
+      int64_t g3 = ((p.n_obs + 3) / 4 + kFitWaves - 1) / kFitWaves;  // four observations per wave
+      if (g3 > 256 * 8) g3 = 256 * 8;
+      const dim3 fg((unsigned)g3), fb(kWave * kFitWaves);
+      switch (p.ws_stride / 64) {
+        case 1: hipLaunchKernelGGL(fit_rows_kernel<1>, fg, fb, 0, stream, q); break;
+        case 2: hipLaunchKernelGGL(fit_rows_kernel<2>, fg, fb, 0, stream, q); break;
+        case 3: hipLaunchKernelGGL(fit_rows_kernel<3>, fg, fb, 0, stream, q); break;
+        default: hipLaunchKernelGGL(fit_rows_kernel<4>, fg, fb, 0, stream, q); break;
+      }
+      e = hipGetLastError();
+      if (e != hipSuccess) return e;
+    }
+  }
+  if (!split) {
+    hipLaunchKernelGGL((wave_loo_kernel<T, VEC, LW, CapsSmall>), dim3((unsigned)grid), dim3(kWave * kWavesPerBlock), 0, stream, p, f);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
   // general kernel over whatever the fast path declined (usually nothing)
   constexpr int BLOCK = 256;
   int64_t g2 = p.n_obs < 1024 ? p.n_obs : 1024;

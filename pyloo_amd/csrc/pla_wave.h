@@ -342,14 +342,14 @@ __device__ __forceinline__ void pad_tail(T (&v)[kWaveSlots], int qfull, int qrem
 // Everything after the sweep: exact selection of the M+1 largest among the candidates, GPD fit,
 // smoothing sums and the outputs.  Shared by the one-chunk and the chunked front ends; `lppd_shift` is
 // the log of the factor by which the chunked front's s2 is short (0 otherwise).
-template <typename T, int VEC, bool LW, typename SM, typename TB>
+template <typename T, int VEC, bool LW, typename SM, typename TB, bool SPLIT = false>
 __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB& tb, const int64_t r, T (&v)[kWaveSlots],
                                           const int lane, const int S, const int M, const int mestM, const double logS,
                                           const int dbgs, const double m, const double mn, const double R,
                                           const double lppd_shift, double s1, double s2, const unsigned ncand,
                                           const int k1, const int sh, const double magic, const double c256,
                                           const int qfull, const int qrem, bool& slow, double& khat, double& loo,
-                                          double& lppd) {
+                                          double& lppd, const FastParams* F = nullptr) {
   constexpr int NQ = kWaveSlots / VEC;
   constexpr int kSa = SM::Caps::kSa;
   const double INF = pinf();
@@ -491,6 +491,24 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
     const double e_cut = exp_tab(xcut, tb.tab);
     double acc_t = 0.0, acc_r = 0.0;  // (sum w' - sum e) and sum w'/e over the tail
     bool smoothed = false;
+    if constexpr (SPLIT) {
+      // ---- split pass: hand the tail over to the lane-per-observation kernel (pla_fit.h) -----------------
+      double s1_all, s2_all;
+      wave_all2<R_SUM>(s1, s2, s1_all, s2_all);
+      double* wy = F->ws_y + r * (int64_t)F->ws_stride;
+      if (n > 4) {
+        // y ascending (psis.py:146-147), zeros from n up to the row stride
+        for (int j = lane; j < F->ws_stride; j += kWave) {
+          const double ej = exp_tab(sb[j < n ? n - 1 - j : 0], tb.tab);
+          wy[j] = j < n ? ej - e_cut : 0.0;
+        }
+      }
+      if (lane == 0) {
+        double* ws = F->ws_s + r * 8;
+        ws[0] = m; ws[1] = mn; ws[2] = s1_all; ws[3] = s2_all; ws[4] = e_cut; ws[5] = (double)n;
+      }
+      return;
+    }
     if (n > 4 && !(dbgs & 8)) {
       wave_sync();
       // y ascending (psis.py:146-147), stored with the pair sums / products the fit loop eats
@@ -758,7 +776,7 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
 // LW = false: LOO mode (input = log-likelihood, raw = -ll; outputs k-hat, loo_i, lppd_i)
 // LW = true:  weights mode (input = log ratios, raw = input; outputs k-hat and the normalised smoothed
 //             log-weights, psis.py:78-111): the row stays in its registers until the weights are stored
-template <typename T, int VEC, bool LW, typename SM, typename TB>
+template <typename T, int VEC, bool LW, typename SM, typename TB, bool SPLIT = false>
 __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParams& F, SM& sm, const TB& tb, const int64_t r,
                                             T (&v)[kWaveSlots], const T* rp_next) {
   constexpr int EPT = kWaveSlots;
@@ -974,8 +992,8 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     } else if ((int)ncand < M + 1 || ncand > (unsigned)kCand) {
       slow = true;  // the speculative threshold missed (too few / too many draws above it)
     } else {
-      wave_back<T, VEC, LW, SM, TB>(P, sm, tb, r, v, lane, S, M, mestM, logS, dbgs, m, mn, R, 0.0, s1, s2, ncand, k1, sh,
-                                    magic, c256, qfull, qrem, slow, khat, loo, lppd);
+      wave_back<T, VEC, LW, SM, TB, SPLIT>(P, sm, tb, r, v, lane, S, M, mestM, logS, dbgs, m, mn, R, 0.0, s1, s2, ncand, k1, sh,
+                                           magic, c256, qfull, qrem, slow, khat, loo, lppd, &F);
     }
   }
   // the next row starts streaming into the (now dead) row registers while the outputs are stored and
@@ -986,7 +1004,8 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     if (slow) {
       const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
       F.slow_list[idx] = (unsigned)r;
-    } else {
+      if constexpr (SPLIT) F.ws_s[r * 8 + 5] = -1.0;  // tail length -1: tells the fit kernel that this observation is on the list
+    } else if constexpr (!SPLIT) {
       if (P.diag) P.diag[r] = khat;
       if constexpr (!LW) {
         if (P.loo_i) P.loo_i[r] = P.scale_value * loo;
@@ -999,7 +1018,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
 // The per-row body is deliberately NOT inlined into the row loop: inlined, LLVM hoists every
 // loop-invariant constant, mask and offset of the later phases above the loop, where they sit on
 // top of the 128 row registers and spill.
-template <typename T, int VEC, bool LW, class CAP>
+template <typename T, int VEC, bool LW, class CAP, bool SPLIT = false>
 __global__ __launch_bounds__(kWave * CAP::kWaves, PLA_MIN_WAVES_PER_SIMD) void wave_loo_kernel(RowsParams P, FastParams F) {
   using SM = std::conditional_t<LW, WaveSmemLWT<CAP>, WaveSmemT<CAP>>;
   using TB = WaveTablesT<CAP>;
@@ -1024,7 +1043,7 @@ __global__ __launch_bounds__(kWave * CAP::kWaves, PLA_MIN_WAVES_PER_SIMD) void w
 #endif
   for (int64_t r = w0; r < P.n_obs; r += nw) {
     const int64_t rn = r + nw;
-    wave_loo_row<T, VEC, LW, SM, TB>(P, F, sm, tb, r, v, rn < P.n_obs ? base + rn * P.stride_obs : nullptr);
+    wave_loo_row<T, VEC, LW, SM, TB, SPLIT>(P, F, sm, tb, r, v, rn < P.n_obs ? base + rn * P.stride_obs : nullptr);
   }
 #if PLA_WAVE_ABLATE
   if (blockIdx.x == 0 && tid == 0) {  // core clock against the 100 MHz real-time counter

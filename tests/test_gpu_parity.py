@@ -380,7 +380,7 @@ def test_weights_device_tensors_full_size(eng):
     res = eng.psis_loo(ll, 190, "psis", 1.0, 0.7)
     torch.cuda.synchronize()
     assert torch.equal(lw, lw_b) and torch.equal(k, k_b)
-    np.testing.assert_allclose(k.cpu().numpy(), res["diag"].cpu().numpy(), rtol=1e-12)
+    np.testing.assert_allclose(k.cpu().numpy(), res["diag"].cpu().numpy(), rtol=1e-9)  # two code paths (fused weights pass, split LOO pass)
     sums = torch.exp(lw).sum(dim=1).cpu().numpy()
     np.testing.assert_allclose(sums, 1.0, rtol=1e-12)
     # loo_i recomputed from the returned weights (loo.py:289,319-324) equals the fused pass

@@ -18,6 +18,9 @@ KERNELS = {
     "wave_loo_kernelIdLi2ELb0ENS_9CapsSmall": 81920,   # LOO, f64
     "wave_loo_kernelIfLi4ELb0ENS_9CapsSmall": 81920,   # LOO, f32
     "wave_loo_kernelIdLi2ELb1ENS_9CapsSmall": 81920,   # weights mode
+    "wave_loo_kernelIdLi2ELb0ENS_9CapsSmallELb1": 81920,   # split pass: selection half
+    "fit_rows_kernelILi3": 81920,                      # split pass: fit half (M = 190)
+    "fit_rows_kernelILi4": 81920,
     "wave_loo_chunked_kernelIdLi2ENS_8CapsMid4": 81920,
     "wave_loo_chunked_kernelIfLi4ENS_7CapsMid": 81920,
     "waic_wave_kernelIdLi2": 81920,
