@@ -13,10 +13,10 @@
 //     (same-address reads: a broadcast);
 //   * reductions are four DPP steps inside the row, never across rows.
 // Same arithmetic as wave_back(): mantissa / exponent accumulators instead of sums of log1p, table-driven
-// exp / log, loo_i from the algebraic shortcut.  Observations with a grid point whose |b_j y_n| < 2^-14 (the
-// product would lose the digits of b_j y), an unusual m_est, factors beyond 2^+-30, sigma <= 0, a tiny khat,
-// a cancelling total or a non-finite result are appended to the device list for the general kernel, like
-// the observations the wave kernel declined.
+// exp / log, loo_i from the algebraic shortcut.  A grid point with |b_j y_n| < 2^-14 (the product would lose
+// the digits of b_j y) takes its sum of log1p from the power sums of the tail instead.  Observations with an
+// unusual m_est, factors beyond 2^+-30, sigma <= 0, a tiny khat, a cancelling total or a non-finite result
+// are appended to the device list for the general kernel, like the observations the wave kernel declined.
 #pragma once
 
 #include "pla_wave.h"
@@ -25,7 +25,11 @@ namespace pla {
 
 constexpr int kFitWaves = 4;       // waves per workgroup (they share the tables)
 constexpr int kFitGrid = 48;       // three grid points per lane: m_est = 30 + isqrt(n) <= 46 for n <= 256
-constexpr int kFitCoefStride = 6;  // doubles per quad in LDS (five used): 48 bytes keep the 16-byte alignment
+constexpr int kFitCoefStride = 6;  // (VALU grid pass) doubles per quad in LDS, five used: 48 bytes keep the 16-byte alignment
+#ifndef PLA_FIT_MFMA
+#define PLA_FIT_MFMA 1  // 1: the quartics of the grid pass on the matrix cores (v_mfma_f64_16x16x4_f64); 0: Horner on the VALU
+#endif
+typedef double v4d __attribute__((ext_vector_type(4)));
 
 struct FitParams {
   const double* ws_y;   // [n_obs][ws_stride] ascending tail values, zero padded; ws_stride = 64 NQ
@@ -64,11 +68,16 @@ __device__ __forceinline__ int row_all_add(int v) {
 }
 
 template <int NQ>
-__global__ __launch_bounds__(kWave * kFitWaves) void fit_rows_kernel(FitParams Q) {
+__global__ __launch_bounds__(kWave * kFitWaves, 2) void fit_rows_kernel(FitParams Q) {
   __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];
   __shared__ __attribute__((aligned(16))) double lt[2 * kLogTabN];
   __shared__ __attribute__((aligned(16))) double l1s[64 * NQ];
+#if PLA_FIT_MFMA
+  constexpr int QN = 16 * NQ;  // quads per observation
+  __shared__ __attribute__((aligned(16))) double coef[kFitWaves * 5 * 4 * QN];  // per wave [coefficient k][observation][quad]
+#else
   __shared__ __attribute__((aligned(16))) double coef[kFitWaves * 4 * 16 * NQ * kFitCoefStride];
+#endif
   const int tid = threadIdx.x;
   const int M = Q.tail_count, S = Q.n_draws, mestM = Q.mest_M;
   for (int j = tid; j < kTabN; j += kWave * kFitWaves) exp_table_entry(tab, j);
@@ -81,7 +90,24 @@ __global__ __launch_bounds__(kWave * kFitWaves) void fit_rows_kernel(FitParams Q
   const auto op_max = [](double a, double b) { return vmax_nc<false>(a, b); };
   const int lane = wave_lane(), t = lane & 15, rho = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+#if PLA_FIT_MFMA
+  double* ck = coef + (size_t)wv * (5 * 4 * QN);
+  // One MFMA evaluates 4 quads x 4 observations x 16 grid points: D[row][col] = C0 + sum_k A[row][k] B[k][col] with
+  // tile row = observation + 4 * quad (so the four results a lane receives, rows rho + 4 i at column t, are four
+  // quads of the lane's OWN observation at its own grid point), A[row][k] = C_(k+1) of that quad and
+  // B[k][col] = g_col^(k+1).  Operand lane (t, rho) supplies A[row t][k rho] and B[k rho][col t].
+  const double* ckA = ck + ((rho + 1) * 4 + (t & 3)) * QN + (t >> 2);
+  const double* ckC = ck + rho * QN;
+  double gp[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int j = t + 16 * c;
+    const double gj = Q.b_grid[j < mestM ? j : 0], g2 = gj * gj;
+    gp[c] = rho == 0 ? gj : (rho == 1 ? g2 : (rho == 2 ? g2 * gj : g2 * g2));
+  }
+#else
   double* cf_row = coef + (size_t)((wv * 4 + rho) * 16 * NQ) * kFitCoefStride;
+#endif
   // grid coordinates of this lane: j = t, t + 16, t + 32
   double g[3];
   bool gact[3];
@@ -130,15 +156,46 @@ __global__ __launch_bounds__(kWave * kFitWaves) void fit_rows_kernel(FitParams Q
       const double t0 = -cb * y0, t1 = -cb * y1, t2 = -cb * y2, t3 = -cb * y3;
       const double A0 = u0 * u1, A1 = fma(u0, t1, u1 * t0), A2 = t0 * t1;
       const double B0 = u2 * u3, B1 = fma(u2, t3, u3 * t2), B2 = t2 * t3;
+#if PLA_FIT_MFMA
+      double* o = ck + rho * QN + (k * 16 + t);
+      o[0] = A0 * B0;
+      o[4 * QN] = fma(A0, B1, A1 * B0);
+      o[8 * QN] = fma(A0, B2, fma(A1, B1, A2 * B0));
+      o[12 * QN] = fma(A1, B2, A2 * B1);
+      o[16 * QN] = A2 * B2;
+#else
       double* o = cf_row + (k * 16 + t) * kFitCoefStride;
       *reinterpret_cast<double2*>(o) = make_double2(A0 * B0, fma(A0, B1, A1 * B0));
       *reinterpret_cast<double2*>(o + 2) = make_double2(fma(A0, B2, fma(A1, B1, A2 * B0)), fma(A1, B2, A2 * B1));
       o[4] = A2 * B2;
+#endif
     }
     wave_sync();
     // ---- grid pass: three running products per lane over the 16 NQ quads of the observation -------------------
     double pm[3] = {1.0, 1.0, 1.0};
     int pe[3] = {0, 0, 0};
+#if PLA_FIT_MFMA
+#pragma unroll 1
+    for (int q4 = 0; q4 < QN; q4 += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; u += 4) {
+        const double a = ckA[q4 + u];
+        const double2 c01 = *reinterpret_cast<const double2*>(ckC + q4 + u), c23 = *reinterpret_cast<const double2*>(ckC + q4 + u + 2);
+        const v4d cin = {c01.x, c01.y, c23.x, c23.y};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const v4d d = __builtin_amdgcn_mfma_f64_16x16x4f64(a, gp[c], cin, 0, 0, 0);
+          pm[c] *= (d[0] * d[1]) * (d[2] * d[3]);
+        }
+      }
+      // factors within 2^+-120 per quad: eight fit between renormalisations
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        pe[c] += __builtin_amdgcn_frexp_exp(pm[c]);
+        pm[c] = __builtin_amdgcn_frexp_mant(pm[c]);
+      }
+    }
+#else
 #pragma unroll 1
     for (int q8 = 0; q8 < 16 * NQ; q8 += 8) {
 #pragma unroll
@@ -156,15 +213,46 @@ __global__ __launch_bounds__(kWave * kFitWaves) void fit_rows_kernel(FitParams Q
         pm[c] = __builtin_amdgcn_frexp_mant(pm[c]);
       }
     }
+#endif
     wave_sync();  // (the next group's coefficients are written after these reads)
     // ---- profile likelihood, softmax weights, posterior mean of b (psis.py:190-201) --------------------------
-    double ls[3], bb[3];
+    double ls[3], bb[3], lp[3];
+    bool tiny[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const double b = fma(g[c], cb, db);
-      bb[c] = b;
-      if (gact[c] && fabs(b * yn) < 0x1p-14) bad = true;  // 1 - b y would round away the digits of b y
-      const double kj = (log_tab(pm[c], lt) + (double)pe[c] * kLn2) * rn;                         // psis.py:190
+      bb[c] = fma(g[c], cb, db);
+      tiny[c] = gact[c] && fabs(bb[c] * yn) < 0x1p-14;  // 1 - b y rounds away the digits of b y
+      lp[c] = log_tab(pm[c], lt) + (double)pe[c] * kLn2;
+    }
+    if (__ballot(tiny[0] || tiny[1] || tiny[2]) != 0ull) {
+      // (one observation in ~2000) sum_i log1p(-b y_i) = -(b p1 + b^2 p2/2 + b^3 p3/3 + b^4 p4/4) + O((b y)^5) from the
+      // power sums p_k of the tail: to 2^-56 relative for |b y| < 2^-14
+      double p1 = 0.0, p2 = 0.0, p3 = 0.0, p4 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 2 * NQ; ++i) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const double yj = e ? yv[i].y : yv[i].x, y2 = yj * yj;
+          p1 += yj;
+          p2 += y2;
+          p3 = fma(y2, yj, p3);
+          p4 = fma(y2, y2, p4);
+        }
+      }
+      p1 = row_all(p1, op_sum);
+      p2 = row_all(p2, op_sum);
+      p3 = row_all(p3, op_sum);
+      p4 = row_all(p4, op_sum);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double b = bb[c];
+        if (tiny[c]) lp[c] = -b * fma(b, fma(b, fma(b, 0.25 * p4, p3 * (1.0 / 3.0)), 0.5 * p2), p1);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double b = bb[c];
+      const double kj = lp[c] * rn;                                                               // psis.py:190
       const double l = nn * (log_tab(gact[c] ? -div_fast(b, kj) : 1.0, lt) - kj - 1.0);           // psis.py:191
       if (gact[c] && l != l) bad = true;  // NaN anywhere: every weight is NaN in the reference; the general kernel does that
       ls[c] = gact[c] ? l : -INF;

@@ -47,10 +47,12 @@ def kernel_stats(lines, pat):
             if op.startswith("s_cbranch") or op == "s_branch":
                 c["branch"] += 1
     res = {}
-    for l in lines[end:end + 80]:
+    for l in lines[end:end + 600]:  # the resource comments follow the kernel descriptor
         m = re.search(r"; (NumVgprs|NumAgprs|ScratchSize|Occupancy|LDSByteSize|NumSgprs): (\d+)", l)
-        if m:
+        if m and m.group(1) not in res:
             res[m.group(1)] = int(m.group(2))
+        if len(res) == 6:
+            break
     return lines[start].split(":")[0], total, phases, res
 
 
