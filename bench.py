@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
 def measured_traffic(n_obs, n_draws, dtype):
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (tools/profile.sh ->
+    """HBM bytes per LOO pass (wave kernel + fit kernel + general kernel) from the rocprofv3 PMC passes (tools/profile.sh ->
     profiles/traffic_latest.json: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), or None
     when no profile of this exact workload is committed."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -138,7 +138,8 @@ def main():
         elapsed = float(tt.item())
     agg = agg.cpu().numpy() if hasattr(agg, "cpu") else np.asarray(agg)
 
-    # ---- roofline of the dominant kernel (the wave kernel + the handful of rows it hands on)
+    # ---- roofline of the LOO pass: wave kernel (selection) + fit kernel + the rows handed to the general kernel,
+    #      timed together with HIP events on the launch stream
     kernel_ms = k_ms / max(k_n, 1)
     alg_bytes = n_local * (S * esz + 24.0)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9

@@ -29,6 +29,9 @@ constexpr int kFitCoefStride = 6;  // (VALU grid pass) doubles per quad in LDS, 
 #ifndef PLA_FIT_MFMA
 #define PLA_FIT_MFMA 1  // 1: the quartics of the grid pass on the matrix cores (v_mfma_f64_16x16x4_f64); 0: Horner on the VALU
 #endif
+#ifndef PLA_FIT_PIN
+#define PLA_FIT_PIN 1  // pairs of tail elements of the smoothing pass the scheduler may interleave
+#endif
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 struct FitParams {
@@ -304,8 +307,9 @@ __global__ __launch_bounds__(kWave * kFitWaves, 2) void fit_rows_kernel(FitParam
       const double ej = yj + e_cut;
       acc_t += (j < n) ? wj - ej : 0.0;
       acc_r += (j < n) ? div_fast(wj, ej) : 0.0;
-      asm volatile("" : "+v"(acc_t), "+v"(acc_r));  // one element at a time: the scheduler would start them all and spill
     };
+    // (the sums are pinned every few elements: left alone, the scheduler starts every element at once and spills)
+    const auto pin = [&]() { asm volatile("" : "+v"(acc_t), "+v"(acc_r)); };
     if (__ballot(fit && n != M) == 0ull) {
       // the usual case, straight-line: log1p(-p_j) from the host table (psis.py:153)
 #pragma unroll
@@ -314,6 +318,7 @@ __global__ __launch_bounds__(kWave * kFitWaves, 2) void fit_rows_kernel(FitParam
         const double2 l1 = *reinterpret_cast<const double2*>(l1s + j);
         smooth(j, l1.x, yv[i].x);
         smooth(j + 1, l1.y, yv[i].y);
+        if ((i % PLA_FIT_PIN) == PLA_FIT_PIN - 1) pin();
       }
     } else {
       // ties shortened some tail of this wave: p_j = (j + 0.5)/n with the observation's own n
@@ -321,6 +326,7 @@ __global__ __launch_bounds__(kWave * kFitWaves, 2) void fit_rows_kernel(FitParam
       for (int i = 0; i < 4 * NQ; ++i) {
         const int j = 16 * i + t;
         smooth(j, n == M ? l1s[j] : log_fast(1.0 - ((double)j + 0.5) * rn), y[j]);
+        pin();
       }
     }
     const double at = row_all(acc_t, op_sum), ar = row_all(acc_r, op_sum);
