@@ -142,6 +142,27 @@ int pla_waic(pla_engine *eng, const void *ll, int dtype, int64_t n_obs, int64_t 
              int64_t stride_obs, int64_t stride_draw, double scale_value, int mem_space, void *stream,
              double *lppd_i, double *var_i, double *waic_i, double *agg);
 
+/*
+ * pla_psis_loo_rows / pla_waic_rows -- the same two passes over a SELECTION of the rows of a resident matrix:
+ * the subsampled LOO of loo_subsample.py:316-330 (`log_likelihood.isel(...)` on the sampled observations, then
+ * compute_importance_weights + logsumexp, 373-386, and the variance over draws of the sampled rows, 389) without
+ * materialising the gathered copy.
+ *
+ *   ll, n_obs, n_draws, strides   the full matrix, as in pla_psis_loo
+ *   row_index  [n_rows] int64 observation indices into the matrix (repeats allowed), in the memory space of `ll`
+ *              (device pointer for PLA_DEVICE).  Host lists are range-checked (PLA_ERR_ARG); device lists are
+ *              clamped into [0, n_obs) on the device before use -- validate them before uploading.
+ *   outputs    compact: entry r belongs to observation row_index[r]; [n_rows] each; agg as in the full-matrix call
+ */
+int pla_psis_loo_rows(pla_engine *eng, const void *ll, int dtype, int64_t n_obs, int64_t n_draws,
+                      int64_t stride_obs, int64_t stride_draw, const int64_t *row_index, int64_t n_rows,
+                      int method, int64_t tail_count, double scale_value, double good_k, int mem_space,
+                      void *stream, double *diag, double *loo_i, double *lppd_i, double *agg);
+int pla_waic_rows(pla_engine *eng, const void *ll, int dtype, int64_t n_obs, int64_t n_draws,
+                  int64_t stride_obs, int64_t stride_draw, const int64_t *row_index, int64_t n_rows,
+                  double scale_value, int mem_space, void *stream, double *lppd_i, double *var_i,
+                  double *waic_i, double *agg);
+
 /* Timing of the dominant kernel, measured with hipEvents on the launch stream.
  * enable != 0 brackets every main-kernel launch with events; pla_engine_kernel_ms returns the
  * accumulated milliseconds and launch count since the last call (it synchronises the events). */

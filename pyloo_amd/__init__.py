@@ -6,10 +6,12 @@ from .base import ISMethod, compute_importance_weights
 from .elpd import ELPDData
 from .loo import loo, loo_from_matrix
 from .loo_i import loo_i
+from .loo_subsample import loo_subsample, loo_subsample_from_matrix
 from .psis import psislw
 from .rcparams import rcParams
 from .waic import waic, waic_from_matrix
 
-__all__ = ["ISMethod", "ELPDData", "compute_importance_weights", "loo", "loo_from_matrix", "loo_i", "psislw", "rcParams", "waic",
+__all__ = ["ISMethod", "ELPDData", "compute_importance_weights", "loo", "loo_from_matrix", "loo_i", "loo_subsample",
+           "loo_subsample_from_matrix", "psislw", "rcParams", "waic",
            "waic_from_matrix"]
 __version__ = "0.1.0"

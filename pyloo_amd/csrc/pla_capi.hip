@@ -56,6 +56,8 @@ struct pla_engine {
   double* d_l1 = nullptr;  // log1p(-(j+0.5)/M), j < M, for the current tail count
   void* d_ws = nullptr;    // hand-over buffers of the split LOO pass: [n][stride] tail values + [n][8] scalars
   size_t d_ws_bytes = 0;
+  void* d_rows = nullptr;  // clamped copy of a caller's device row-index list
+  size_t d_rows_bytes = 0;
   size_t d_l1_bytes = 0;
   int64_t l1_M = -1;
   // timing of the main kernel
@@ -208,6 +210,7 @@ int pla_engine_destroy(pla_engine* e) {
   if (e->d_slow) (void)hipFree(e->d_slow);
   if (e->d_l1) (void)hipFree(e->d_l1);
   if (e->d_ws) (void)hipFree(e->d_ws);
+  if (e->d_rows) (void)hipFree(e->d_rows);
   for (int i = 0; i < pla_engine::kTimingRing; ++i) {
     if (e->ev0[i]) (void)hipEventDestroy(e->ev0[i]);
     if (e->ev1[i]) (void)hipEventDestroy(e->ev1[i]);
@@ -273,11 +276,52 @@ int pla_reduce_pointwise(pla_engine* eng, const double* diag, const double* loo_
   return PLA_OK;
 }
 
-int pla_psis_loo(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int64_t n_draws, int64_t stride_obs,
-                 int64_t stride_draw, int method, int64_t tail_count, double scale_value, double good_k,
-                 int mem_space, void* stream, double* diag, double* loo_i, double* lppd_i, double* agg) {
-  int rc = check_common(eng, ll, dtype, n_obs, n_draws, stride_obs, stride_draw, method, tail_count, mem_space);
+// row selection shared by pla_psis_loo_rows / pla_waic_rows: the index list lives where the matrix lives
+static int check_rows(const int64_t* row_index, int64_t n_rows, int64_t n_src, int mem_space) {
+  if (n_rows < 0) return fail(PLA_ERR_ARG, "n_rows < 0");
+  if (n_rows > 0 && !row_index) return fail(PLA_ERR_ARG, "row_index is NULL");
+  if (n_rows > 0 && n_src <= 0) return fail(PLA_ERR_ARG, "row selection from an empty matrix");
+  if (mem_space == PLA_HOST)
+    for (int64_t i = 0; i < n_rows; ++i)
+      if (row_index[i] < 0 || row_index[i] >= n_src) return fail(PLA_ERR_ARG, "row_index out of range");
+  return PLA_OK;
+}
+
+// device path: a clamped copy of the caller's index list in engine memory (the row kernels trust it)
+static int device_rows(pla_engine* eng, const int64_t* row_index, int64_t n_rows, int64_t n_src, hipStream_t s,
+                       const int64_t** out) {
+  int rc = grow(&eng->d_rows, &eng->d_rows_bytes, (size_t)(n_rows > 0 ? n_rows : 1) * sizeof(int64_t));
   if (rc) return rc;
+  PLA_HIP(pla::launch_clamp_rows(row_index, n_rows, n_src, (int64_t*)eng->d_rows, s));
+  *out = (const int64_t*)eng->d_rows;
+  return PLA_OK;
+}
+
+// host path: pack rows [r0, r0 + nr) of the call (selected rows when row_index is set) into the staging buffer
+static int stage_rows(pla_engine* eng, const void* ll, const int64_t* row_index, int64_t r0, int64_t nr, int64_t stride_obs,
+                      size_t esz, size_t row_bytes, hipStream_t s) {
+  if (!row_index) {
+    const char* src = (const char*)ll + (size_t)r0 * stride_obs * esz;
+    PLA_HIP(hipMemcpy2DAsync(eng->d_in, row_bytes, src, (size_t)stride_obs * esz, row_bytes, (size_t)nr, hipMemcpyHostToDevice, s));
+  } else {
+    for (int64_t i = 0; i < nr; ++i)
+      PLA_HIP(hipMemcpyAsync((char*)eng->d_in + (size_t)i * row_bytes, (const char*)ll + (size_t)row_index[r0 + i] * stride_obs * esz,
+                             row_bytes, hipMemcpyHostToDevice, s));
+  }
+  return PLA_OK;
+}
+
+static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_src, const int64_t* row_index, int64_t n_obs,
+                         int64_t n_draws, int64_t stride_obs, int64_t stride_draw, int method, int64_t tail_count,
+                         double scale_value, double good_k, int mem_space, void* stream, double* diag, double* loo_i,
+                         double* lppd_i, double* agg) {
+  // (n_obs = observations of this call: the selected rows when row_index is set, else all n_src rows)
+  int rc = check_common(eng, ll, dtype, n_src, n_draws, stride_obs, stride_draw, method, tail_count, mem_space);
+  if (rc) return rc;
+  if (row_index || n_obs != n_src) {
+    rc = check_rows(row_index, n_obs, n_src, mem_space);
+    if (rc) return rc;
+  }
   PLA_HIP(hipSetDevice(eng->device));
   hipStream_t s = (hipStream_t)stream;
   const size_t esz = dtype == PLA_F64 ? 8 : 4;
@@ -329,6 +373,10 @@ int pla_psis_loo(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int6
     p.in = ll;
     p.stride_obs = stride_obs;
     p.stride_draw = stride_draw;
+    if (row_index) {
+      rc = device_rows(eng, row_index, n_obs, n_src, s, &p.row_index);
+      if (rc) return rc;
+    }
     p.diag = dd;
     p.loo_i = dl;
     p.lppd_i = dp;
@@ -373,11 +421,10 @@ int pla_psis_loo(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int6
   }
   for (int64_t r0 = 0; r0 < n_obs; r0 += rows_per_chunk) {
     const int64_t nr = (n_obs - r0 < rows_per_chunk) ? (n_obs - r0) : rows_per_chunk;
-    const char* src = (const char*)ll + (size_t)r0 * stride_obs * esz;
     // pack to (nr, S) contiguous on the device; strided sources use a pitched copy
     if (stride_draw == 1) {
-      PLA_HIP(hipMemcpy2DAsync(eng->d_in, row_bytes, src, (size_t)stride_obs * esz, row_bytes, (size_t)nr,
-                               hipMemcpyHostToDevice, s));
+      rc = stage_rows(eng, ll, row_index, r0, nr, stride_obs, esz, row_bytes, s);
+      if (rc) return rc;
       p.stride_obs = n_draws;
       p.stride_draw = 1;
     } else {
@@ -406,6 +453,22 @@ int pla_psis_loo(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int6
   }
   PLA_HIP(hipStreamSynchronize(s));
   return PLA_OK;
+}
+
+int pla_psis_loo(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int64_t n_draws, int64_t stride_obs,
+                 int64_t stride_draw, int method, int64_t tail_count, double scale_value, double good_k,
+                 int mem_space, void* stream, double* diag, double* loo_i, double* lppd_i, double* agg) {
+  return psis_loo_impl(eng, ll, dtype, n_obs, nullptr, n_obs, n_draws, stride_obs, stride_draw, method, tail_count, scale_value,
+                       good_k, mem_space, stream, diag, loo_i, lppd_i, agg);
+}
+
+int pla_psis_loo_rows(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int64_t n_draws, int64_t stride_obs,
+                      int64_t stride_draw, const int64_t* row_index, int64_t n_rows, int method, int64_t tail_count,
+                      double scale_value, double good_k, int mem_space, void* stream, double* diag, double* loo_i,
+                      double* lppd_i, double* agg) {
+  if (n_rows > 0 && !row_index) return fail(PLA_ERR_ARG, "row_index is NULL");
+  return psis_loo_impl(eng, ll, dtype, n_obs, row_index, n_rows, n_draws, stride_obs, stride_draw, method, tail_count,
+                       scale_value, good_k, mem_space, stream, diag, loo_i, lppd_i, agg);
 }
 
 int pla_importance_weights(pla_engine* eng, const void* logw, int dtype, int64_t n_obs, int64_t n_draws,
@@ -489,11 +552,15 @@ int pla_importance_weights(pla_engine* eng, const void* logw, int dtype, int64_t
   return PLA_OK;
 }
 
-int pla_waic(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int64_t n_draws, int64_t stride_obs,
-             int64_t stride_draw, double scale_value, int mem_space, void* stream, double* lppd_i, double* var_i,
-             double* waic_i, double* agg) {
-  int rc = check_common(eng, ll, dtype, n_obs, n_draws, stride_obs, stride_draw, PLA_SIS, 0, mem_space);
+static int waic_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_src, const int64_t* row_index, int64_t n_obs,
+                     int64_t n_draws, int64_t stride_obs, int64_t stride_draw, double scale_value, int mem_space, void* stream,
+                     double* lppd_i, double* var_i, double* waic_i, double* agg) {
+  int rc = check_common(eng, ll, dtype, n_src, n_draws, stride_obs, stride_draw, PLA_SIS, 0, mem_space);
   if (rc) return rc;
+  if (row_index || n_obs != n_src) {
+    rc = check_rows(row_index, n_obs, n_src, mem_space);
+    if (rc) return rc;
+  }
   PLA_HIP(hipSetDevice(eng->device));
   hipStream_t s = (hipStream_t)stream;
   const size_t esz = dtype == PLA_F64 ? 8 : 4;
@@ -511,7 +578,12 @@ int pla_waic(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int64_t 
     }
     {
       TimedLaunch t(eng, s);
-      PLA_HIP(pla::launch_waic(ll, dtype, n_obs, (int)n_draws, stride_obs, stride_draw, scale_value, dl, dv, dw,
+      const int64_t* rows_d = nullptr;
+      if (row_index) {
+        rc = device_rows(eng, row_index, n_obs, n_src, s, &rows_d);
+        if (rc) return rc;
+      }
+      PLA_HIP(pla::launch_waic(ll, rows_d, dtype, n_obs, (int)n_draws, stride_obs, stride_draw, scale_value, dl, dv, dw,
                                eng->counters + 1, s));
     }
     if (agg) {
@@ -542,12 +614,11 @@ int pla_waic(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int64_t 
   }
   for (int64_t r0 = 0; r0 < n_obs; r0 += rows_per_chunk) {
     const int64_t nr = (n_obs - r0 < rows_per_chunk) ? (n_obs - r0) : rows_per_chunk;
-    const char* src = (const char*)ll + (size_t)r0 * stride_obs * esz;
-    PLA_HIP(hipMemcpy2DAsync(eng->d_in, row_bytes, src, (size_t)stride_obs * esz, row_bytes, (size_t)nr,
-                             hipMemcpyHostToDevice, s));
+    rc = stage_rows(eng, ll, row_index, r0, nr, stride_obs, esz, row_bytes, s);
+    if (rc) return rc;
     {
       TimedLaunch t(eng, s);
-      PLA_HIP(pla::launch_waic(eng->d_in, dtype, nr, (int)n_draws, n_draws, 1, scale_value, dl + r0, dv + r0, dw + r0,
+      PLA_HIP(pla::launch_waic(eng->d_in, nullptr, dtype, nr, (int)n_draws, n_draws, 1, scale_value, dl + r0, dv + r0, dw + r0,
                                eng->counters + 1, s));
     }
     PLA_HIP(hipStreamSynchronize(s));  // the staging buffer is reused by the next chunk
@@ -564,6 +635,21 @@ int pla_waic(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int64_t 
   }
   PLA_HIP(hipStreamSynchronize(s));
   return PLA_OK;
+}
+
+int pla_waic(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int64_t n_draws, int64_t stride_obs,
+             int64_t stride_draw, double scale_value, int mem_space, void* stream, double* lppd_i, double* var_i,
+             double* waic_i, double* agg) {
+  return waic_impl(eng, ll, dtype, n_obs, nullptr, n_obs, n_draws, stride_obs, stride_draw, scale_value, mem_space, stream,
+                   lppd_i, var_i, waic_i, agg);
+}
+
+int pla_waic_rows(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int64_t n_draws, int64_t stride_obs,
+                  int64_t stride_draw, const int64_t* row_index, int64_t n_rows, double scale_value, int mem_space,
+                  void* stream, double* lppd_i, double* var_i, double* waic_i, double* agg) {
+  if (n_rows > 0 && !row_index) return fail(PLA_ERR_ARG, "row_index is NULL");
+  return waic_impl(eng, ll, dtype, n_obs, row_index, n_rows, n_draws, stride_obs, stride_draw, scale_value, mem_space, stream,
+                   lppd_i, var_i, waic_i, agg);
 }
 
 int pla_fill_synthetic(pla_engine* eng, void* ll_device, int dtype, int64_t n_obs, int64_t n_draws, int64_t row0,

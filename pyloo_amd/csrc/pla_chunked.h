@@ -26,7 +26,7 @@ constexpr int kChunkDraws = kWave * kWaveSlots;  // 4096
 
 template <typename T, int VEC, typename SM, typename TB>
 __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const FastParams& F, SM& sm, const TB& tb,
-                                                    const int64_t r, T (&v)[kWaveSlots], const T* rp_next) {
+                                                    const int64_t r, T (&v)[kWaveSlots], const T* row, const T* rp_next) {
   constexpr int EPT = kWaveSlots;
   constexpr int NQ = EPT / VEC;
   constexpr int kCand = SM::Caps::kCand;
@@ -41,7 +41,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
   const double logS = uniform_d(F.log_S);
   const double INF = pinf();
   const int nch = (S + kChunkDraws - 1) / kChunkDraws;
-  const T* row = reinterpret_cast<const T*>(P.in) + r * P.stride_obs;
 
   double magic = kMagic, c256 = kC256;
   asm volatile("" : "+v"(magic));
@@ -240,10 +239,13 @@ __global__ __launch_bounds__(kWave * CAP::kWaves, 1) void wave_loo_chunked_kerne
   const T* base = reinterpret_cast<const T*>(P.in);
   const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + wv, nw = (int64_t)gridDim.x * kWavesPerBlock;
   const int first = P.n_draws < kChunkDraws ? P.n_draws : kChunkDraws;
-  if (w0 < P.n_obs) issue_row_loads<T, VEC>(v, base + w0 * P.stride_obs, first);
+  const T* cur = w0 < P.n_obs ? base + PLA_ROW_OFFSET(P, w0) : nullptr;
+  if (cur) issue_row_loads<T, VEC>(v, cur, first);
   for (int64_t r = w0; r < P.n_obs; r += nw) {
     const int64_t rn = r + nw;
-    wave_loo_row_chunked<T, VEC, SM, TB>(P, F, sm, tb, r, v, rn < P.n_obs ? base + rn * P.stride_obs : nullptr);
+    const T* nxt = rn < P.n_obs ? base + PLA_ROW_OFFSET(P, rn) : nullptr;
+    wave_loo_row_chunked<T, VEC, SM, TB>(P, F, sm, tb, r, v, cur, nxt);
+    cur = nxt;
   }
 }
 

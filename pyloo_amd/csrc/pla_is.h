@@ -33,10 +33,10 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void is_wave_kernel(Rows
   const T* base = reinterpret_cast<const T*>(P.in);
   const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + wv, nw = (int64_t)gridDim.x * kWavesPerBlock;
   T v[kWaveSlots];
-  if (w0 < P.n_obs) issue_row_loads<T, VEC>(v, base + w0 * P.stride_obs, S);
+  if (w0 < P.n_obs) issue_row_loads<T, VEC>(v, base + PLA_ROW_OFFSET(P, w0), S);
   for (int64_t r = w0; r < P.n_obs; r += nw) {
     const int64_t rn = r + nw;
-    const T* rp_next = rn < P.n_obs ? base + rn * P.stride_obs : nullptr;
+    const T* rp_next = rn < P.n_obs ? base + PLA_ROW_OFFSET(P, rn) : nullptr;
     const __amdgpu_buffer_rsrc_t rs_next = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>(rp_next ? rp_next : base), 0, rp_next ? S * (int)sizeof(T) : 0, 0x00020000);
     const int nvec = __builtin_amdgcn_readfirstlane(P.n_draws) / VEC;  // (kept inside the loop: see pla_waic.h)

@@ -27,7 +27,13 @@ struct RowsParams {
   double* ws_y = nullptr;        // [n_obs][ws_stride]
   double* ws_s = nullptr;        // [n_obs][8]
   int ws_stride = 0;
+  // optional row selection (loo_subsample, loo_subsample.py:316-330): observation r of this call is row row_index[r] of `in`;
+  // outputs stay compact ([n_obs] = number of selected rows)
+  const int64_t* row_index = nullptr;  // (already clamped into the matrix: launch_clamp_rows)
 };
+
+// element offset of observation r's row in the input matrix
+#define PLA_ROW_OFFSET(P, r) (((P).row_index ? (P).row_index[(r)] : (int64_t)(r)) * (P).stride_obs)
 
 struct ReduceParams {
   const double* diag;
@@ -42,12 +48,14 @@ struct ReduceParams {
 // returns hipSuccess or the launch error; never synchronises
 hipError_t launch_rows(const RowsParams& p, int dtype, bool lw_mode, hipStream_t stream);
 hipError_t launch_reduce(const ReduceParams& p, double* workspace, hipStream_t stream);
+// out[i] = min(max(in[i], 0), n_src - 1): a caller's device index list can never make a row kernel read outside the matrix
+hipError_t launch_clamp_rows(const int64_t* in, int64_t n_rows, int64_t n_src, int64_t* out, hipStream_t stream);
 int reduce_workspace_doubles();  // size of `workspace` (device memory)
 hipError_t launch_fill_synthetic(void* ll, int dtype, int64_t n_obs, int64_t n_draws, int64_t row0,
                                  uint64_t seed, double k_lo, double k_hi, double heavy_lo,
                                  double heavy_hi, hipStream_t stream);
 // WAIC pass (waic.py:109-160): lppd_i, var_i, waic_i per observation; `replaced` counts NaN/inf entries
-hipError_t launch_waic(const void* in, int dtype, int64_t n_obs, int n_draws, int64_t stride_obs, int64_t stride_draw,
+hipError_t launch_waic(const void* in, const int64_t* row_index, int dtype, int64_t n_obs, int n_draws, int64_t stride_obs, int64_t stride_draw,
                        double scale_value, double* lppd_i, double* var_i, double* waic_i,
                        unsigned long long* replaced, hipStream_t stream);
 // largest tail count the kernels accept

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(BLOCK) void rows_kernel(RowsParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const Smem sm = carve<BLOCK>(smem_raw, P.tail_cap);
   for (int64_t r = blockIdx.x; r < P.n_obs; r += gridDim.x) {
-    const T* rp = reinterpret_cast<const T*>(P.in) + r * P.stride_obs;
+    const T* rp = reinterpret_cast<const T*>(P.in) + PLA_ROW_OFFSET(P, r);
     if constexpr (EPT == 0) {
       RowGlobal<T, !LW> row{rp, P.stride_draw, P.n_draws};
       process_row<RowGlobal<T, !LW>, T, BLOCK, LW>(row, P, sm, r);
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(BLOCK) void slow_rows_kernel(RowsParams P) {
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&P.counters[1], count);  // running total of this call
   for (unsigned long long i = blockIdx.x; i < count; i += gridDim.x) {
     const int64_t r = (int64_t)P.slow_list[i];
-    const T* rp = reinterpret_cast<const T*>(P.in) + r * P.stride_obs;
+    const T* rp = reinterpret_cast<const T*>(P.in) + PLA_ROW_OFFSET(P, r);
     RowGlobal<T, !LW> row{rp, P.stride_draw, P.n_draws};
     process_row<RowGlobal<T, !LW>, T, BLOCK, LW>(row, P, sm, r);
   }
@@ -385,11 +385,26 @@ static hipError_t launch_waic_typed(const WaicParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-hipError_t launch_waic(const void* in, int dtype, int64_t n_obs, int n_draws, int64_t stride_obs, int64_t stride_draw,
+__global__ void clamp_rows_kernel(const int64_t* in, int64_t n_rows, int64_t n_src, int64_t* out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = in[i];
+    out[i] = v < 0 ? 0 : (v >= n_src ? n_src - 1 : v);
+  }
+}
+
+hipError_t launch_clamp_rows(const int64_t* in, int64_t n_rows, int64_t n_src, int64_t* out, hipStream_t stream) {
+  if (n_rows <= 0) return hipSuccess;
+  int64_t g = (n_rows + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(clamp_rows_kernel, dim3((unsigned)g), dim3(256), 0, stream, in, n_rows, n_src, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_waic(const void* in, const int64_t* row_index, int dtype, int64_t n_obs, int n_draws, int64_t stride_obs, int64_t stride_draw,
                        double scale_value, double* lppd_i, double* var_i, double* waic_i,
                        unsigned long long* replaced, hipStream_t stream) {
   if (n_obs <= 0) return hipSuccess;
-  WaicParams p{in, n_obs, n_draws, stride_obs, stride_draw, scale_value, lppd_i, var_i, waic_i, replaced};
+  WaicParams p{in, n_obs, n_draws, stride_obs, stride_draw, scale_value, lppd_i, var_i, waic_i, replaced, row_index};
   return dtype == PLA_F64 ? launch_waic_typed<double>(p, stream) : launch_waic_typed<float>(p, stream);
 }
 

@@ -27,6 +27,7 @@ struct WaicParams {
   double* var_i;    // [n_obs] or null
   double* waic_i;   // [n_obs] or null
   unsigned long long* replaced;  // [1] device counter: NaN / inf entries replaced (may be null)
+  const int64_t* row_index = nullptr;  // optional row selection, as in RowsParams
 };
 
 // waic.py:112-135
@@ -56,11 +57,11 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void waic_wave_kernel(Wa
   const T* base = reinterpret_cast<const T*>(P.in);
   const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + wv, nw = (int64_t)gridDim.x * kWavesPerBlock;
   T v[kWaveSlots];
-  if (w0 < P.n_obs) issue_row_loads<T, VEC>(v, base + w0 * P.stride_obs, S);
+  if (w0 < P.n_obs) issue_row_loads<T, VEC>(v, base + PLA_ROW_OFFSET(P, w0), S);
   unsigned nrep = 0;
   for (int64_t r = w0; r < P.n_obs; r += nw) {
     const int64_t rn = r + nw;
-    const T* rp_next = rn < P.n_obs ? base + rn * P.stride_obs : nullptr;
+    const T* rp_next = rn < P.n_obs ? base + PLA_ROW_OFFSET(P, rn) : nullptr;
     // (read through readfirstlane inside the loop: otherwise the 31 per-vector masks of pad_tail are
     // hoisted out of the row loop and spill)
     const int nvec = __builtin_amdgcn_readfirstlane(P.n_draws) / VEC;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(BLOCK) void waic_rows_kernel(WaicParams P) {
   const int S = P.n_draws;
   unsigned nrep = 0;
   for (int64_t r = blockIdx.x; r < P.n_obs; r += gridDim.x) {
-    const T* rp = reinterpret_cast<const T*>(P.in) + r * P.stride_obs;
+    const T* rp = reinterpret_cast<const T*>(P.in) + PLA_ROW_OFFSET(P, r);
     double mx = -pinf(), sum = 0.0;
     for (int s = tid; s < S; s += BLOCK) {
       const double x = (double)waic_sanitize(rp[(int64_t)s * P.stride_draw], nrep);

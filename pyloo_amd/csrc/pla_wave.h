@@ -898,7 +898,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     // the next row (a zero-length range when there is none: the loads then return zeros and touch nothing)
     // (weights mode streams the SAME row in again: its raw values are needed once more for the final
     // pass, and holding them through selection and fit would spill)
-    const T* rp_stream = LW ? reinterpret_cast<const T*>(P.in) + r * P.stride_obs : rp_next;
+    const T* rp_stream = LW ? reinterpret_cast<const T*>(P.in) + PLA_ROW_OFFSET(P, r) : rp_next;
     const __amdgpu_buffer_rsrc_t rs_next = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>(rp_stream ? rp_stream : (const T*)P.in), 0, rp_stream ? S * (int)sizeof(T) : 0, 0x00020000);
     streamed = !LW;  // weights mode: the next row is requested after the weights have been stored
@@ -1036,14 +1036,14 @@ __global__ __launch_bounds__(kWave * CAP::kWaves, PLA_MIN_WAVES_PER_SIMD) void w
   T v[kWaveSlots];
   const T* base = reinterpret_cast<const T*>(P.in);
   const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + wv, nw = (int64_t)gridDim.x * kWavesPerBlock;
-  if (w0 < P.n_obs) issue_row_loads<T, VEC, LW ? 0 : PLA_LOAD_AUX>(v, base + w0 * P.stride_obs, P.n_draws);
+  if (w0 < P.n_obs) issue_row_loads<T, VEC, LW ? 0 : PLA_LOAD_AUX>(v, base + PLA_ROW_OFFSET(P, w0), P.n_draws);
 #if PLA_WAVE_ABLATE
   unsigned long long ck0, rt0;
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck0), "=s"(rt0));
 #endif
   for (int64_t r = w0; r < P.n_obs; r += nw) {
     const int64_t rn = r + nw;
-    wave_loo_row<T, VEC, LW, SM, TB, SPLIT>(P, F, sm, tb, r, v, rn < P.n_obs ? base + rn * P.stride_obs : nullptr);
+    wave_loo_row<T, VEC, LW, SM, TB, SPLIT>(P, F, sm, tb, r, v, rn < P.n_obs ? base + PLA_ROW_OFFSET(P, rn) : nullptr);
   }
 #if PLA_WAVE_ABLATE
   if (blockIdx.x == 0 && tid == 0) {  // core clock against the 100 MHz real-time counter

@@ -84,18 +84,31 @@ class Engine:
         return t
 
     # ------------------------------------------------------------------ LOO pass
-    def psis_loo(self, ll, tail_count=0, method="psis", scale_value=1.0, good_k=0.7, pointwise=True, aggregate=True):
+    def psis_loo(self, ll, tail_count=0, method="psis", scale_value=1.0, good_k=0.7, pointwise=True, aggregate=True,
+                 rows=None):
         """Fused pass over an (n_obs, n_draws) log-likelihood matrix (``pla_psis_loo``).
 
         Returns ``dict(diag, loo_i, lppd_i, agg)`` -- NumPy arrays for NumPy input, CUDA tensors
         for CUDA-tensor input (``agg`` included; nothing is synchronised in that case).
+        ``rows``: optional observation indices; the pass then runs over those rows only
+        (``pla_psis_loo_rows``) and the outputs have one entry per index.
         """
         mcode = METHOD_CODES[method]
         if _is_torch_tensor(ll):
-            return self._psis_loo_device(ll, tail_count, mcode, scale_value, good_k, pointwise, aggregate)
+            return self._psis_loo_device(ll, tail_count, mcode, scale_value, good_k, pointwise, aggregate, rows)
         a = self._as_2d_host(ll)
         n, s = a.shape
         so = a.strides[0] // a.itemsize if n > 1 else s
+        if rows is not None:
+            idx = self._host_rows(rows, n)
+            m = idx.size
+            diag, loo_i, lppd_i = (np.empty(m), np.empty(m), np.empty(m)) if pointwise else (None, None, None)
+            agg = np.zeros(AGG_COUNT) if aggregate else None
+            p = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)  # noqa: E731
+            check(self._lib.pla_psis_loo_rows(self._h, a.ctypes.data_as(C.c_void_p), dtype_code(a.dtype), n, s, so, 1,
+                                              p(idx), m, mcode, int(tail_count), float(scale_value), float(good_k),
+                                              PLA_HOST, None, p(diag), p(loo_i), p(lppd_i), p(agg)))
+            return {"diag": diag, "loo_i": loo_i, "lppd_i": lppd_i, "agg": agg}
         diag = np.empty(n) if pointwise else None
         loo_i = np.empty(n) if pointwise else None
         lppd_i = np.empty(n) if pointwise else None
@@ -106,7 +119,23 @@ class Engine:
                                      None, p(diag), p(loo_i), p(lppd_i), p(agg)))
         return {"diag": diag, "loo_i": loo_i, "lppd_i": lppd_i, "agg": agg}
 
-    def _psis_loo_device(self, t, tail_count, mcode, scale_value, good_k, pointwise, aggregate):
+    @staticmethod
+    def _host_rows(rows, n_obs):
+        """Index list as contiguous int64, range-checked like NumPy indexing would (no negative wrap-around:
+        loo_subsample.py:266-271 rejects indices outside [0, n))."""
+        idx = np.ascontiguousarray(np.asarray(rows).reshape(-1), dtype=np.int64)
+        if idx.size and (idx.min() < 0 or idx.max() >= n_obs):
+            raise IndexError(f"row indices must lie in [0, {n_obs}), got range [{idx.min()}, {idx.max()}]")
+        return idx
+
+    def _device_rows(self, rows, n_obs, device):
+        import torch
+
+        if _is_torch_tensor(rows):  # already on the device: the kernels clamp, the caller vouches for the range
+            return rows.to(device=device, dtype=torch.int64).contiguous().reshape(-1)
+        return torch.from_numpy(self._host_rows(rows, n_obs)).to(device)
+
+    def _psis_loo_device(self, t, tail_count, mcode, scale_value, good_k, pointwise, aggregate, rows=None):
         import torch
 
         if t.dim() != 2 or not t.is_cuda:
@@ -116,12 +145,19 @@ class Engine:
         t = self._draws_fastest(t)
         n, s = t.shape
         dev = t.device
-        diag = torch.empty(n, dtype=torch.float64, device=dev) if (pointwise or aggregate) else None
-        loo_i = torch.empty(n, dtype=torch.float64, device=dev) if (pointwise or aggregate) else None
-        lppd_i = torch.empty(n, dtype=torch.float64, device=dev) if (pointwise or aggregate) else None
+        idx = None if rows is None else self._device_rows(rows, n, dev)
+        m = n if idx is None else idx.numel()
+        diag = torch.empty(m, dtype=torch.float64, device=dev) if (pointwise or aggregate) else None
+        loo_i = torch.empty(m, dtype=torch.float64, device=dev) if (pointwise or aggregate) else None
+        lppd_i = torch.empty(m, dtype=torch.float64, device=dev) if (pointwise or aggregate) else None
         agg = torch.zeros(AGG_COUNT, dtype=torch.float64, device=dev) if aggregate else None
         p = lambda x: None if x is None else C.c_void_p(x.data_ptr())  # noqa: E731
         code = _capi.PLA_F64 if t.dtype == torch.float64 else _capi.PLA_F32
+        if idx is not None:
+            check(self._lib.pla_psis_loo_rows(self._h, C.c_void_p(t.data_ptr()), code, n, s, t.stride(0), t.stride(1),
+                                              p(idx), m, mcode, int(tail_count), float(scale_value), float(good_k),
+                                              PLA_DEVICE, self._stream(), p(diag), p(loo_i), p(lppd_i), p(agg)))
+            return {"diag": diag, "loo_i": loo_i, "lppd_i": lppd_i, "agg": agg}
         check(self._lib.pla_psis_loo(self._h, C.c_void_p(t.data_ptr()), code, n, s, t.stride(0), t.stride(1),
                                      mcode, int(tail_count), float(scale_value), float(good_k), PLA_DEVICE,
                                      self._stream(), p(diag), p(loo_i), p(lppd_i), p(agg)))
@@ -154,9 +190,10 @@ class Engine:
         return lw, diag
 
     # ------------------------------------------------------------------ WAIC pass
-    def waic(self, ll, scale_value=1.0, pointwise=True, aggregate=True):
+    def waic(self, ll, scale_value=1.0, pointwise=True, aggregate=True, rows=None):
         """(n_obs, n_draws) log-likelihood -> ``dict(lppd_i, var_i, waic_i, agg)`` (``pla_waic``; the
-        slots of ``agg`` are documented in include/pyloo_amd.h)."""
+        slots of ``agg`` are documented in include/pyloo_amd.h).  ``rows``: optional observation indices
+        (``pla_waic_rows``), one output entry per index."""
         if _is_torch_tensor(ll):
             import torch
 
@@ -167,20 +204,33 @@ class Engine:
                 raise TypeError(f"unsupported dtype {t.dtype}")
             t = self._draws_fastest(t)
             n, s = t.shape
-            mk = lambda: torch.empty(n, dtype=torch.float64, device=t.device)  # noqa: E731
+            idx = None if rows is None else self._device_rows(rows, n, t.device)
+            m = n if idx is None else idx.numel()
+            mk = lambda: torch.empty(m, dtype=torch.float64, device=t.device)  # noqa: E731
             lppd_i, var_i, waic_i = (mk(), mk(), mk()) if (pointwise or aggregate) else (None, None, None)
             agg = torch.zeros(AGG_COUNT, dtype=torch.float64, device=t.device) if aggregate else None
             p = lambda x: None if x is None else C.c_void_p(x.data_ptr())  # noqa: E731
             code = _capi.PLA_F64 if t.dtype == torch.float64 else _capi.PLA_F32
+            if idx is not None:
+                check(self._lib.pla_waic_rows(self._h, C.c_void_p(t.data_ptr()), code, n, s, t.stride(0), t.stride(1),
+                                              p(idx), m, float(scale_value), PLA_DEVICE, self._stream(), p(lppd_i),
+                                              p(var_i), p(waic_i), p(agg)))
+                return {"lppd_i": lppd_i, "var_i": var_i, "waic_i": waic_i, "agg": agg}
             check(self._lib.pla_waic(self._h, C.c_void_p(t.data_ptr()), code, n, s, t.stride(0), t.stride(1),
                                      float(scale_value), PLA_DEVICE, self._stream(), p(lppd_i), p(var_i), p(waic_i), p(agg)))
             return {"lppd_i": lppd_i, "var_i": var_i, "waic_i": waic_i, "agg": agg}
         a = self._as_2d_host(ll)
         n, s = a.shape
         so = a.strides[0] // a.itemsize if n > 1 else s
-        lppd_i, var_i, waic_i = (np.empty(n), np.empty(n), np.empty(n)) if pointwise else (None, None, None)
+        idx = None if rows is None else self._host_rows(rows, n)
+        m = n if idx is None else idx.size
+        lppd_i, var_i, waic_i = (np.empty(m), np.empty(m), np.empty(m)) if pointwise else (None, None, None)
         agg = np.zeros(AGG_COUNT) if aggregate else None
         p = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)  # noqa: E731
+        if idx is not None:
+            check(self._lib.pla_waic_rows(self._h, a.ctypes.data_as(C.c_void_p), dtype_code(a.dtype), n, s, so, 1, p(idx), m,
+                                          float(scale_value), PLA_HOST, None, p(lppd_i), p(var_i), p(waic_i), p(agg)))
+            return {"lppd_i": lppd_i, "var_i": var_i, "waic_i": waic_i, "agg": agg}
         check(self._lib.pla_waic(self._h, a.ctypes.data_as(C.c_void_p), dtype_code(a.dtype), n, s, so, 1,
                                  float(scale_value), PLA_HOST, None, p(lppd_i), p(var_i), p(waic_i), p(agg)))
         return {"lppd_i": lppd_i, "var_i": var_i, "waic_i": waic_i, "agg": agg}

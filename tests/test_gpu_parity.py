@@ -102,7 +102,9 @@ def test_known_answer(eng):
 @pytest.mark.parametrize("S,N,reff,dt", [(4000, 96, 1.0, np.float64), (1000, 64, 0.6, np.float64),
                                          (257, 40, 1.0, np.float64), (64, 33, 2.0, np.float64),
                                          (6000, 24, 1.0, np.float64), (20000, 12, 1.0, np.float32),
-                                         (4000, 50, 0.25, np.float32)])
+                                         (4000, 50, 0.25, np.float32),
+                                         # tail counts 230 / 222 / 124: the four- and two-quad variants of the fit kernel
+                                         (4096, 40, 0.7, np.float64), (3000, 30, 0.55, np.float32), (2048, 37, 1.2, np.float64)])
 def test_seeded_vs_oracle(eng, S, N, reff, dt):
     rng = np.random.default_rng(S * 7 + N)
     k = rng.uniform(0.05, 1.2, size=N)
