@@ -345,7 +345,7 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
       p.l1_table = eng->d_l1;
       // hand-over buffers of the split pass (one-chunk wave kernel -> fit kernel, pla_fit.h): sized for the
       // rows one launch processes (all of them on the device path, one staging chunk on the host path)
-      if (tail_count <= 250 && n_draws <= 4096) {
+      if (tail_count <= 250 && n_draws >= 256 && n_draws <= 4096) {  // (the shapes the one-chunk wave kernel takes)
         const int64_t chunk_rows = (int64_t)(((size_t)1 << 30) / ((size_t)n_draws * esz));
         const int64_t rows = mem_space == PLA_DEVICE ? n_obs : (chunk_rows < 1 ? 1 : (chunk_rows < n_obs ? chunk_rows : n_obs));
         const int stride = (int)((tail_count + 63) & ~(int64_t)63);  // 16 lanes x 4 values per quad
