@@ -168,6 +168,9 @@ int pla_waic_rows(pla_engine *eng, const void *ll, int dtype, int64_t n_obs, int
  * accumulated milliseconds and launch count since the last call (it synchronises the events). */
 int pla_engine_set_timing(pla_engine *eng, int enable);
 int pla_engine_kernel_ms(pla_engine *eng, double *total_ms, int64_t *launches);
+/* Same, for the first (dominant) kernel alone of the passes that ran as two kernels (the split PSIS-LOO pass: the
+ * wave kernel up to the tail selection); device-pointer calls only.  Read it before or after pla_engine_kernel_ms. */
+int pla_engine_first_kernel_ms(pla_engine *eng, double *total_ms, int64_t *launches);
 
 /* Synthetic benchmark input, generated on the device:
  *   u = splitmix64(seed ^ (i*S + s)) -> 53-bit uniform in (0,1) -> E = -log1p(-u)

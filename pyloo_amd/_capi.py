@@ -19,7 +19,7 @@ SYMBOLS = (
     "pla_abi_version", "pla_last_error", "pla_device_count", "pla_engine_create", "pla_engine_destroy",
     "pla_tail_count", "pla_psis_loo", "pla_importance_weights", "pla_reduce_pointwise", "pla_waic",
     "pla_psis_loo_rows", "pla_waic_rows",
-    "pla_engine_set_timing", "pla_engine_kernel_ms", "pla_fill_synthetic",
+    "pla_engine_set_timing", "pla_engine_kernel_ms", "pla_engine_first_kernel_ms", "pla_fill_synthetic",
 )
 
 
@@ -71,6 +71,7 @@ def load_library():
     lib.pla_waic_rows.argtypes = [vp, vp, ci, i64, i64, i64, i64, vp, i64, dbl, ci, vp, vp, vp, vp, vp]
     lib.pla_engine_set_timing.argtypes = [vp, ci]
     lib.pla_engine_kernel_ms.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
+    lib.pla_engine_first_kernel_ms.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
     lib.pla_fill_synthetic.argtypes = [vp, vp, ci, i64, i64, i64, C.c_uint64, dbl, dbl, dbl, dbl, vp]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError if the header and the library disagree

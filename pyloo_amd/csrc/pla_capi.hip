@@ -63,8 +63,11 @@ struct pla_engine {
   // timing of the main kernel
   bool timing = false;
   static constexpr int kTimingRing = 64;  // launches timed without a host-side wait in between
-  hipEvent_t ev0[kTimingRing] = {}, ev1[kTimingRing] = {};
+  hipEvent_t ev0[kTimingRing] = {}, ev1[kTimingRing] = {}, evm[kTimingRing] = {};  // evm: after the first kernel of a split pass
+  bool has_mid[kTimingRing] = {};
   double acc_ms = 0.0;
+  double acc_first_ms = 0.0;  // first (dominant) kernel of split passes only
+  long long first_launches = 0;
   int64_t launches = 0;
   int pending = 0;  // event pairs recorded and not yet read back
 };
@@ -136,6 +139,12 @@ struct TimedLaunch {  // brackets the main kernel with events when timing is on
       (void)hipEventRecord(e->ev0[e->pending], s);
     }
   }
+  hipEvent_t mid() const { return e->timing ? e->evm[e->pending] : nullptr; }
+  bool* mid_flag() const {
+    if (!e->timing) return nullptr;
+    e->has_mid[e->pending] = false;
+    return &e->has_mid[e->pending];
+  }
   ~TimedLaunch() {
     if (e->timing) {
       (void)hipEventRecord(e->ev1[e->pending], s);
@@ -148,6 +157,10 @@ struct TimedLaunch {  // brackets the main kernel with events when timing is on
       if (hipEventSynchronize(e->ev1[i]) == hipSuccess && hipEventElapsedTime(&ms, e->ev0[i], e->ev1[i]) == hipSuccess) {
         e->acc_ms += ms;
         e->launches += 1;
+        if (e->has_mid[i] && hipEventElapsedTime(&ms, e->ev0[i], e->evm[i]) == hipSuccess) {
+          e->acc_first_ms += ms;
+          e->first_launches += 1;
+        }
       }
     }
     e->pending = 0;
@@ -190,6 +203,7 @@ int pla_engine_create(int device, pla_engine** out) {
   for (int i = 0; i < pla_engine::kTimingRing && he == hipSuccess; ++i) {
     he = hipEventCreate(&e->ev0[i]);
     if (he == hipSuccess) he = hipEventCreate(&e->ev1[i]);
+    if (he == hipSuccess) he = hipEventCreate(&e->evm[i]);
   }
   if (he != hipSuccess) {
     pla_engine_destroy(e);
@@ -214,6 +228,7 @@ int pla_engine_destroy(pla_engine* e) {
   for (int i = 0; i < pla_engine::kTimingRing; ++i) {
     if (e->ev0[i]) (void)hipEventDestroy(e->ev0[i]);
     if (e->ev1[i]) (void)hipEventDestroy(e->ev1[i]);
+    if (e->evm[i]) (void)hipEventDestroy(e->evm[i]);
   }
   delete e;
   return PLA_OK;
@@ -242,6 +257,16 @@ int pla_engine_kernel_ms(pla_engine* e, double* total_ms, int64_t* launches) {
   if (launches) *launches = e->launches;
   e->acc_ms = 0.0;
   e->launches = 0;
+  return PLA_OK;
+}
+
+int pla_engine_first_kernel_ms(pla_engine* e, double* total_ms, int64_t* launches) {
+  if (!e) return fail(PLA_ERR_ARG, "engine is NULL");
+  TimedLaunch::flush(e);
+  if (total_ms) *total_ms = e->acc_first_ms;
+  if (launches) *launches = e->first_launches;
+  e->acc_first_ms = 0.0;
+  e->first_launches = 0;
   return PLA_OK;
 }
 
@@ -382,7 +407,7 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
     p.lppd_i = dp;
     {
       TimedLaunch t(eng, s);
-      PLA_HIP(pla::launch_rows(p, dtype, false, s));
+      PLA_HIP(pla::launch_rows(p, dtype, false, s, t.mid(), t.mid_flag()));
     }
 #if defined(PLA_WAVE_ABLATE) && PLA_WAVE_ABLATE
     if (getenv("PLA_PRINT_CLOCK")) {  // profiling build only: core clock seen by one wave of the fast kernel

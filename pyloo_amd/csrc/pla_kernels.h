@@ -46,7 +46,10 @@ struct ReduceParams {
 };
 
 // returns hipSuccess or the launch error; never synchronises
-hipError_t launch_rows(const RowsParams& p, int dtype, bool lw_mode, hipStream_t stream);
+// `after_first`: optional event recorded right after the first kernel of a split LOO pass (timing of the dominant kernel alone);
+// *recorded is set when it was
+hipError_t launch_rows(const RowsParams& p, int dtype, bool lw_mode, hipStream_t stream, hipEvent_t after_first = nullptr,
+                       bool* recorded = nullptr);
 hipError_t launch_reduce(const ReduceParams& p, double* workspace, hipStream_t stream);
 // out[i] = min(max(in[i], 0), n_src - 1): a caller's device index list can never make a row kernel read outside the matrix
 hipError_t launch_clamp_rows(const int64_t* in, int64_t n_rows, int64_t n_src, int64_t* out, hipStream_t stream);

@@ -223,7 +223,7 @@ static int debug_flag(const char* name) {
 }
 
 template <typename T, int VEC, bool LW>
-static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, hipStream_t stream) {
+static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, hipStream_t stream, hipEvent_t after_first, bool* recorded) {
   hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   static const int dbg = debug_flag("PLA_DEBUG_SKIP");
@@ -250,6 +250,7 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, hipStream_t 
                          stream, p, f);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
+      if (after_first && hipEventRecord(after_first, stream) == hipSuccess && recorded) *recorded = true;
       FitParams q{p.ws_y, p.ws_s, p.ws_stride, p.n_obs, p.n_draws, p.tail_count, mestM, f.log_S, p.scale_value, p.l1_table,
                   p.l1_table + p.tail_count, p.diag, p.loo_i, p.lppd_i, p.slow_list, p.counters};
       int64_t g3 = ((p.n_obs + 3) / 4 + kFitWaves - 1) / kFitWaves;  // four observations per wave
@@ -322,7 +323,7 @@ static hipError_t launch_is(const RowsParams& p, hipStream_t stream) {
 }
 
 template <typename T, bool LW>
-static hipError_t launch_typed(const RowsParams& p, hipStream_t stream) {
+static hipError_t launch_typed(const RowsParams& p, hipStream_t stream, hipEvent_t after_first, bool* recorded) {
   constexpr int BLOCK = 256;
   const bool unit = (p.stride_draw == 1);
   {
@@ -335,7 +336,7 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream) {
         smem_bytes(BLOCK, p.tail_cap) <= 64 * 1024 && p.n_obs <= 0xffffffffll) {
       int gsz = 0, kq = 0;
       if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq)) {
-        return launch_wave<T, WVEC, LW>(p, gsz, kq, stream);
+        return launch_wave<T, WVEC, LW>(p, gsz, kq, stream, after_first, recorded);
       }
     }
     if constexpr (!LW) {
@@ -362,10 +363,10 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream) {
   return launch_one<T, BLOCK, 0, LW>(p, stream);
 }
 
-hipError_t launch_rows(const RowsParams& p, int dtype, bool lw_mode, hipStream_t stream) {
+hipError_t launch_rows(const RowsParams& p, int dtype, bool lw_mode, hipStream_t stream, hipEvent_t after_first, bool* recorded) {
   if (p.n_obs <= 0) return hipSuccess;
-  if (dtype == PLA_F64) return lw_mode ? launch_typed<double, true>(p, stream) : launch_typed<double, false>(p, stream);
-  return lw_mode ? launch_typed<float, true>(p, stream) : launch_typed<float, false>(p, stream);
+  if (dtype == PLA_F64) return lw_mode ? launch_typed<double, true>(p, stream, after_first, recorded) : launch_typed<double, false>(p, stream, after_first, recorded);
+  return lw_mode ? launch_typed<float, true>(p, stream, after_first, recorded) : launch_typed<float, false>(p, stream, after_first, recorded);
 }
 
 template <typename T>

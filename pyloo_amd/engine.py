@@ -270,6 +270,12 @@ class Engine:
         check(self._lib.pla_engine_kernel_ms(self._h, C.byref(ms), C.byref(k)))
         return ms.value, k.value
 
+    def first_kernel_ms(self):
+        """Accumulated time of the first (dominant) kernel of the two-kernel PSIS-LOO passes since the last call."""
+        ms, k = C.c_double(0), C.c_int64(0)
+        check(self._lib.pla_engine_first_kernel_ms(self._h, C.byref(ms), C.byref(k)))
+        return ms.value, k.value
+
 
 def get_engine(device=None):
     """Process-wide engine for ``device`` (default: torch's current CUDA device, else 0)."""
