@@ -23,7 +23,7 @@ struct RowsParams {
   unsigned long long* counters;  // [4] device counters: [0] rows left to the general kernel
   unsigned* slow_list;           // [n_obs] workspace for the fast path (may be null: general kernel only)
   const double* l1_table;        // [tail_count] log1p(-(j+0.5)/M), then [64] 1 - sqrt(m_est/(j+0.5)) (host-computed)
-  // hand-over buffers of the split LOO pass (wave kernel -> lane-per-observation fit); null: fused pass
+  // hand-over buffers of the split LOO pass (wave kernel -> fit kernel, pla_fit.h); null: fused pass
   double* ws_y = nullptr;        // [n_obs][ws_stride]
   double* ws_s = nullptr;        // [n_obs][8]
   int ws_stride = 0;

@@ -492,7 +492,7 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
     double acc_t = 0.0, acc_r = 0.0;  // (sum w' - sum e) and sum w'/e over the tail
     bool smoothed = false;
     if constexpr (SPLIT) {
-      // ---- split pass: hand the tail over to the lane-per-observation kernel (pla_fit.h) -----------------
+      // ---- split pass: hand the tail over to the fit kernel (pla_fit.h: 16 lanes per observation) -----------------
       double s1_all, s2_all;
       wave_all2<R_SUM>(s1, s2, s1_all, s2_all);
       double* wy = F->ws_y + r * (int64_t)F->ws_stride;
