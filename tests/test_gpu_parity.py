@@ -566,3 +566,31 @@ def test_odd_shapes(eng, N, S, dt):
     w = eng.waic(ll, 1.0)
     wr = orc.waic_arrays(ll.astype(np.float64), 1)
     np.testing.assert_allclose(w["waic_i"], wr["waic_i"], rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("S,reff", [(4000, 1.0), (2048, 1.2), (4096, 0.7)])
+def test_fit_kernel_branches(eng, S, reff):
+    """Rows that steer the fit kernel of the split pass off its straight-line path: ties at the cutoff that shorten the
+    tail a little (p_j from the observation's own n, same grid) or a lot (another m_est: handed to the general kernel),
+    repeated draws inside the tail, and tails of very different weight side by side in one wavefront."""
+    rng = np.random.default_rng(S)
+    N = 48
+    M = orc.tail_count(S, reff)
+    k = np.tile([0.05, 0.3, 0.7, 1.1], N // 4)[:, None]
+    ll = -k * rng.exponential(size=(N, S)) + rng.normal(size=(N, 1))
+    order = np.argsort(ll, axis=1)  # ascending ll = descending log ratio: the tail is the first M entries
+    for i in range(N):
+        o = order[i]
+        if i % 4 == 1:      # the cutoff value repeated 3 times inside the tail: n = M - 3
+            ll[i, o[M - 3:M]] = ll[i, o[M]]
+        elif i % 4 == 2:    # ... 40 times: n = M - 40, isqrt changes for the tail counts used here
+            ll[i, o[M - 40:M]] = ll[i, o[M]]
+        elif i % 4 == 3:    # repeated draws inside the tail (a Metropolis chain that stood still)
+            ll[i, o[5:9]] = ll[i, o[4]]
+            ll[i, o[60:62]] = ll[i, o[59]]
+    ref = orc.loo_arrays(ll, reff)
+    res = eng.psis_loo(ll, M, "psis", 1.0, ref["good_k"])
+    close(res["diag"], ref["khat"], what="khat")
+    close(res["loo_i"], ref["loo_i"], what="loo_i")
+    close(res["lppd_i"], ref["lppd_i"], what="lppd_i")
+    np.testing.assert_allclose(res["agg"][1], ref["elpd_loo"], rtol=RTOL)
