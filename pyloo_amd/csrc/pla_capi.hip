@@ -301,6 +301,20 @@ int pla_reduce_pointwise(pla_engine* eng, const double* diag, const double* loo_
   return PLA_OK;
 }
 
+// Device matrices with the observations fastest (ArviZ's native layout behind pyloo's stacked view, loo.py:189) are brought
+// to draws-fastest row blocks by a tiled transpose kernel and then take the same kernels as everything else.
+static bool obs_fastest_device(int mem_space, const int64_t* row_index, int64_t n_src, int64_t n_draws, int64_t stride_obs,
+                               int64_t stride_draw) {
+  return mem_space == PLA_DEVICE && !row_index && n_src > 1 && n_draws > 1 && stride_obs == 1 && stride_draw >= n_src;
+}
+// rows per staging block: 1 GiB blocks from the host (pinned-copy granularity), 4 GiB for the device transpose
+static int64_t staged_chunk_rows(int mem_space, bool ingest, int64_t n_obs, int64_t n_draws, size_t esz) {
+  const size_t bytes = (size_t)1 << ((mem_space == PLA_DEVICE && ingest) ? 32 : 30);
+  int64_t r = (int64_t)(bytes / ((size_t)n_draws * esz));
+  if (r < 1) r = 1;
+  return r < n_obs ? r : n_obs;
+}
+
 // row selection shared by pla_psis_loo_rows / pla_waic_rows: the index list lives where the matrix lives
 static int check_rows(const int64_t* row_index, int64_t n_rows, int64_t n_src, int mem_space) {
   if (n_rows < 0) return fail(PLA_ERR_ARG, "n_rows < 0");
@@ -350,6 +364,7 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
   PLA_HIP(hipSetDevice(eng->device));
   hipStream_t s = (hipStream_t)stream;
   const size_t esz = dtype == PLA_F64 ? 8 : 4;
+  const bool ingest = obs_fastest_device(mem_space, row_index, n_src, n_draws, stride_obs, stride_draw);
 
   pla::RowsParams p{};
   p.n_obs = n_obs;
@@ -371,8 +386,8 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
       // hand-over buffers of the split pass (one-chunk wave kernel -> fit kernel, pla_fit.h): sized for the
       // rows one launch processes (all of them on the device path, one staging chunk on the host path)
       if (tail_count <= 250 && n_draws >= 256 && n_draws <= 4096) {  // (the shapes the one-chunk wave kernel takes)
-        const int64_t chunk_rows = (int64_t)(((size_t)1 << 30) / ((size_t)n_draws * esz));
-        const int64_t rows = mem_space == PLA_DEVICE ? n_obs : (chunk_rows < 1 ? 1 : (chunk_rows < n_obs ? chunk_rows : n_obs));
+        const int64_t chunk_rows = staged_chunk_rows(mem_space, ingest, n_obs, n_draws, esz);
+        const int64_t rows = (mem_space == PLA_DEVICE && !ingest) ? n_obs : chunk_rows;
         const int stride = (int)((tail_count + 63) & ~(int64_t)63);  // 16 lanes x 4 values per quad
         rc = grow(&eng->d_ws, &eng->d_ws_bytes, (size_t)rows * (size_t)(stride + 8) * sizeof(double));
         if (rc) return rc;
@@ -394,6 +409,31 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
       if (!dd) dd = eng->d_pw;
       if (!dl) dl = eng->d_pw + n_obs;
       if (!dp) dp = eng->d_pw + 2 * n_obs;
+    }
+    if (ingest) {
+      // observations-fastest input: transpose a block of rows into the staging buffer, run the pass on it, next block
+      // (all on the caller's stream: the buffer is reused in stream order, nothing synchronises)
+      const int64_t rows_per_chunk = staged_chunk_rows(mem_space, true, n_obs, n_draws, esz);
+      rc = grow(&eng->d_in, &eng->d_in_bytes, (size_t)rows_per_chunk * (size_t)n_draws * esz);
+      if (rc) return rc;
+      p.in = eng->d_in;
+      p.stride_obs = n_draws;
+      p.stride_draw = 1;
+      for (int64_t r0 = 0; r0 < n_obs; r0 += rows_per_chunk) {
+        const int64_t nr = (n_obs - r0 < rows_per_chunk) ? (n_obs - r0) : rows_per_chunk;
+        TimedLaunch t(eng, s);
+        PLA_HIP(pla::launch_transpose_rows(ll, dtype, stride_draw, r0, nr, (int)n_draws, eng->d_in, s));
+        p.n_obs = nr;
+        p.diag = dd ? dd + r0 : nullptr;
+        p.loo_i = dl ? dl + r0 : nullptr;
+        p.lppd_i = dp ? dp + r0 : nullptr;
+        PLA_HIP(pla::launch_rows(p, dtype, false, s));
+      }
+      if (agg) {
+        pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, agg, eng->counters + 1};
+        PLA_HIP(pla::launch_reduce(rp, eng->d_red, s));
+      }
+      return PLA_OK;
     }
     p.in = ll;
     p.stride_obs = stride_obs;
@@ -601,7 +641,18 @@ static int waic_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_src, 
       if (!dv) dv = eng->d_pw;
       if (!dw) dw = eng->d_pw + n_obs;
     }
-    {
+    if (obs_fastest_device(mem_space, row_index, n_src, n_draws, stride_obs, stride_draw)) {
+      const int64_t rows_per_chunk = staged_chunk_rows(mem_space, true, n_obs, n_draws, esz);
+      rc = grow(&eng->d_in, &eng->d_in_bytes, (size_t)rows_per_chunk * (size_t)n_draws * esz);
+      if (rc) return rc;
+      for (int64_t r0 = 0; r0 < n_obs; r0 += rows_per_chunk) {
+        const int64_t nr = (n_obs - r0 < rows_per_chunk) ? (n_obs - r0) : rows_per_chunk;
+        TimedLaunch t(eng, s);
+        PLA_HIP(pla::launch_transpose_rows(ll, dtype, stride_draw, r0, nr, (int)n_draws, eng->d_in, s));
+        PLA_HIP(pla::launch_waic(eng->d_in, nullptr, dtype, nr, (int)n_draws, n_draws, 1, scale_value, dl ? dl + r0 : nullptr,
+                                 dv ? dv + r0 : nullptr, dw ? dw + r0 : nullptr, eng->counters + 1, s));
+      }
+    } else {
       TimedLaunch t(eng, s);
       const int64_t* rows_d = nullptr;
       if (row_index) {

@@ -54,6 +54,11 @@ hipError_t launch_reduce(const ReduceParams& p, double* workspace, hipStream_t s
 // out[i] = min(max(in[i], 0), n_src - 1): a caller's device index list can never make a row kernel read outside the matrix
 hipError_t launch_clamp_rows(const int64_t* in, int64_t n_rows, int64_t n_src, int64_t* out, hipStream_t stream);
 int reduce_workspace_doubles();  // size of `workspace` (device memory)
+// Observations-fastest ingestion: ArviZ keeps log-likelihoods as (chain, draw, *obs), so the
+// (obs, sample) view pyloo stacks (loo.py:189) has unit stride along the observations.  Rows [obs0, obs0 + n_rows) of
+// such a matrix (element (i, s) at in[s * stride_draw + i]) are written as a contiguous (n_rows, n_draws) block.
+hipError_t launch_transpose_rows(const void* in, int dtype, int64_t stride_draw, int64_t obs0, int64_t n_rows, int n_draws,
+                                 void* out, hipStream_t stream);
 hipError_t launch_fill_synthetic(void* ll, int dtype, int64_t n_obs, int64_t n_draws, int64_t row0,
                                  uint64_t seed, double k_lo, double k_hi, double heavy_lo,
                                  double heavy_hi, hipStream_t stream);

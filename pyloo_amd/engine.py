@@ -71,9 +71,9 @@ class Engine:
     @staticmethod
     def _draws_fastest(t):
         """ArviZ keeps log-likelihoods as (chain, draw, *obs): the (obs, sample) view of such a buffer has the
-        observations fastest.  The wave kernels want unit stride along the draws, so such a view is
-        transposed on the device first (one extra read + write of the matrix, still ~10x faster than
-        walking it with a stride); if that copy does not fit, the strided general kernel takes it."""
+        observations fastest.  The LOO and WAIC entry points of the library take that layout as it is (a tiled
+        transpose kernel feeds the row kernels block by block); the weights pass still wants unit stride along the
+        draws, so there such a view is copied first (if the copy does not fit, the strided general kernel takes it)."""
         import torch
 
         if t.dim() == 2 and t.shape[1] > 1 and t.stride(1) != 1:
@@ -82,6 +82,14 @@ class Engine:
             except torch.OutOfMemoryError:  # pragma: no cover - needs a nearly full device
                 return t
         return t
+
+    @staticmethod
+    def _library_layout(t, rows=None):
+        """Layouts the LOO / WAIC passes read fast without a copy: draws fastest, or observations fastest (stride 1 along
+        the observations, no row selection); anything else goes through :meth:`_draws_fastest`."""
+        if t.dim() == 2 and t.shape[0] > 1 and t.shape[1] > 1 and t.stride(0) == 1 and t.stride(1) >= t.shape[0] and rows is None:
+            return t
+        return Engine._draws_fastest(t)
 
     # ------------------------------------------------------------------ LOO pass
     def psis_loo(self, ll, tail_count=0, method="psis", scale_value=1.0, good_k=0.7, pointwise=True, aggregate=True,
@@ -142,7 +150,7 @@ class Engine:
             raise ValueError("expected a 2-D CUDA tensor")
         if t.dtype not in (torch.float64, torch.float32):
             raise TypeError(f"unsupported dtype {t.dtype}")
-        t = self._draws_fastest(t)
+        t = self._library_layout(t, rows)
         n, s = t.shape
         dev = t.device
         idx = None if rows is None else self._device_rows(rows, n, dev)
@@ -202,7 +210,7 @@ class Engine:
                 raise ValueError("expected a 2-D CUDA tensor")
             if t.dtype not in (torch.float64, torch.float32):
                 raise TypeError(f"unsupported dtype {t.dtype}")
-            t = self._draws_fastest(t)
+            t = self._library_layout(t, rows)
             n, s = t.shape
             idx = None if rows is None else self._device_rows(rows, n, t.device)
             m = n if idx is None else idx.numel()

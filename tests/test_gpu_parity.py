@@ -532,7 +532,7 @@ def test_loo_i_front(eng):
 
 
 def test_observation_fastest_device_layout(eng):
-    """(S, N) buffer viewed as (N, S) -- the ArviZ-native layout: transposed on the device, then the fast path."""
+    """(S, N) buffer viewed as (N, S) -- the ArviZ-native layout: transposed block by block inside the library, then the fast path."""
     import torch
 
     rng = np.random.default_rng(21)
@@ -547,6 +547,29 @@ def test_observation_fastest_device_layout(eng):
     assert int(res["agg"][7].item()) == 0                       # the wave kernel took every row
     lw, k = eng.importance_weights(-view, 190, "psis")
     close(lw.cpu().numpy(), ref["lw"], what="lw")
+
+
+@pytest.mark.parametrize("N,S,dt", [(500, 4000, np.float64), (130, 1000, np.float32), (67, 258, np.float64), (2, 4096, np.float64),
+                                    (1000, 8000, np.float32)])
+def test_observation_fastest_ingestion(eng, N, S, dt):
+    """The library's own transposing ingestion (64 x 64 tiles): ragged tile edges, both dtypes, LOO and WAIC passes give the
+    bits of the draws-fastest copy."""
+    import torch
+
+    rng = np.random.default_rng(N + S)
+    ll = (-rng.uniform(0.1, 0.9, size=(N, 1)) * rng.exponential(size=(N, S)) - 0.5).astype(dt)
+    M = orc.tail_count(S, 1.0)
+    rowmajor = torch.from_numpy(ll).cuda()
+    view = torch.from_numpy(np.ascontiguousarray(ll.T)).cuda().T   # (N, S) view of an (S, N) buffer
+    assert view.stride(0) == 1 and view.stride(1) == N
+    a, b = eng.psis_loo(view, M, "psis", 1.0, 0.7), eng.psis_loo(rowmajor, M, "psis", 1.0, 0.7)
+    for key in ("diag", "loo_i", "lppd_i", "agg"):
+        np.testing.assert_array_equal(a[key].cpu().numpy(), b[key].cpu().numpy(), err_msg=key)
+    wa, wb = eng.waic(view, 1.0), eng.waic(rowmajor, 1.0)
+    for key in ("lppd_i", "var_i", "waic_i", "agg"):
+        np.testing.assert_array_equal(wa[key].cpu().numpy(), wb[key].cpu().numpy(), err_msg=key)
+    sub = eng.psis_loo(view, M, "psis", 1.0, 0.7, rows=np.array([N - 1, 0]))   # (row selection on such a view: copied first)
+    np.testing.assert_array_equal(sub["loo_i"].cpu().numpy(), b["loo_i"].cpu().numpy()[[N - 1, 0]])
 
 
 @pytest.mark.parametrize("N", [1, 2, 3, 5, 63, 65])
