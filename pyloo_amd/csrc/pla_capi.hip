@@ -309,7 +309,12 @@ static bool obs_fastest_device(int mem_space, const int64_t* row_index, int64_t 
 }
 // rows per staging block: 1 GiB blocks from the host (pinned-copy granularity), 4 GiB for the device transpose
 static int64_t staged_chunk_rows(int mem_space, bool ingest, int64_t n_obs, int64_t n_draws, size_t esz) {
-  const size_t bytes = (size_t)1 << ((mem_space == PLA_DEVICE && ingest) ? 32 : 30);
+  static const size_t ingest_bytes = [] {  // PLA_INGEST_BLOCK_MB: block size of the transposing ingestion (tuning knob)
+    const char* e = getenv("PLA_INGEST_BLOCK_MB");
+    const long mb = e ? atol(e) : 0;
+    return mb > 0 ? (size_t)mb << 20 : (size_t)1 << 32;
+  }();
+  const size_t bytes = (mem_space == PLA_DEVICE && ingest) ? ingest_bytes : (size_t)1 << 30;
   int64_t r = (int64_t)(bytes / ((size_t)n_draws * esz));
   if (r < 1) r = 1;
   return r < n_obs ? r : n_obs;
