@@ -17,8 +17,10 @@
  *     stages through its own device buffers) or PLA_DEVICE (pointers are HIP device
  *     pointers on the engine's device, work is enqueued on `stream`, no host sync).
  *   - matrices are (n_obs, n_draws) with element strides (stride_obs, stride_draw) in
- *     ELEMENTS; the fast path wants stride_draw == 1 ("S-contiguous", pyloo's stacked
- *     `(*obs, __sample__)` view, loo.py:189).
+ *     ELEMENTS.  Two layouts are fast: stride_draw == 1 (draws contiguous), and stride_obs == 1 with
+ *     stride_draw >= n_obs (observations contiguous: pyloo's stacked `(*obs, __sample__)` view of an ArviZ
+ *     (chain, draw, *obs) array, loo.py:189) -- pla_psis_loo and pla_waic transpose the latter block by block on
+ *     the device.  Anything else runs on the strided general kernel (device pointers) or is refused (host pointers).
  *   - an engine is bound to one device; calls on one engine must be serialised by the
  *     caller, different engines are independent (no hidden global state).
  */

@@ -57,6 +57,8 @@ struct pla_engine {
   void* d_ws = nullptr;    // hand-over buffers of the split LOO pass: [n][stride] tail values + [n][8] scalars
   size_t d_ws_bytes = 0;
   void* d_rows = nullptr;  // clamped copy of a caller's device row-index list
+  void* d_slab = nullptr;  // host path, observations-fastest input: (n_draws, block of observations) slab before the transpose
+  size_t d_slab_bytes = 0;
   size_t d_rows_bytes = 0;
   size_t d_l1_bytes = 0;
   int64_t l1_M = -1;
@@ -225,6 +227,7 @@ int pla_engine_destroy(pla_engine* e) {
   if (e->d_l1) (void)hipFree(e->d_l1);
   if (e->d_ws) (void)hipFree(e->d_ws);
   if (e->d_rows) (void)hipFree(e->d_rows);
+  if (e->d_slab) (void)hipFree(e->d_slab);
   for (int i = 0; i < pla_engine::kTimingRing; ++i) {
     if (e->ev0[i]) (void)hipEventDestroy(e->ev0[i]);
     if (e->ev1[i]) (void)hipEventDestroy(e->ev1[i]);
@@ -343,7 +346,20 @@ static int device_rows(pla_engine* eng, const int64_t* row_index, int64_t n_rows
 
 // host path: pack rows [r0, r0 + nr) of the call (selected rows when row_index is set) into the staging buffer
 static int stage_rows(pla_engine* eng, const void* ll, const int64_t* row_index, int64_t r0, int64_t nr, int64_t stride_obs,
-                      size_t esz, size_t row_bytes, hipStream_t s) {
+                      size_t esz, size_t row_bytes, hipStream_t s, int64_t stride_draw = 1, int dtype = PLA_F64,
+                      int64_t rows_per_chunk = 0) {
+  if (stride_draw != 1) {
+    // observations fastest on the host (a (chain, draw, *obs) array viewed as (obs, sample), loo.py:189): the block of
+    // observations goes up as an (n_draws, nr) slab -- one pitched copy, no transpose on the host -- and is transposed
+    // on the device
+    const int64_t n_draws = (int64_t)(row_bytes / esz);
+    int rc = grow(&eng->d_slab, &eng->d_slab_bytes, (size_t)rows_per_chunk * row_bytes);
+    if (rc) return rc;
+    PLA_HIP(hipMemcpy2DAsync(eng->d_slab, (size_t)nr * esz, (const char*)ll + (size_t)r0 * esz, (size_t)stride_draw * esz,
+                             (size_t)nr * esz, (size_t)n_draws, hipMemcpyHostToDevice, s));
+    PLA_HIP(pla::launch_transpose_rows(eng->d_slab, dtype, nr, 0, nr, (int)n_draws, eng->d_in, s));
+    return PLA_OK;
+  }
   if (!row_index) {
     const char* src = (const char*)ll + (size_t)r0 * stride_obs * esz;
     PLA_HIP(hipMemcpy2DAsync(eng->d_in, row_bytes, src, (size_t)stride_obs * esz, row_bytes, (size_t)nr, hipMemcpyHostToDevice, s));
@@ -492,13 +508,14 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
   for (int64_t r0 = 0; r0 < n_obs; r0 += rows_per_chunk) {
     const int64_t nr = (n_obs - r0 < rows_per_chunk) ? (n_obs - r0) : rows_per_chunk;
     // pack to (nr, S) contiguous on the device; strided sources use a pitched copy
-    if (stride_draw == 1) {
-      rc = stage_rows(eng, ll, row_index, r0, nr, stride_obs, esz, row_bytes, s);
+    if (stride_draw == 1 || (stride_obs == 1 && stride_draw >= n_src && !row_index)) {
+      rc = stage_rows(eng, ll, row_index, r0, nr, stride_obs, esz, row_bytes, s, stride_draw, dtype, rows_per_chunk);
       if (rc) return rc;
       p.stride_obs = n_draws;
       p.stride_draw = 1;
     } else {
-      return fail(PLA_ERR_UNSUPPORTED, "PLA_HOST input needs stride_draw == 1 (transpose on the host)");
+      return fail(PLA_ERR_UNSUPPORTED, "PLA_HOST input needs unit stride along the draws, or along the observations without "
+                                       "a row selection");
     }
     p.in = eng->d_in;
     p.n_obs = nr;
@@ -674,7 +691,9 @@ static int waic_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_src, 
     return PLA_OK;
   }
 
-  if (stride_draw != 1) return fail(PLA_ERR_UNSUPPORTED, "PLA_HOST input needs stride_draw == 1 (transpose on the host)");
+  if (stride_draw != 1 && !(stride_obs == 1 && stride_draw >= n_src && !row_index))
+    return fail(PLA_ERR_UNSUPPORTED, "PLA_HOST input needs unit stride along the draws, or along the observations without a "
+                                     "row selection");
   {
     size_t have_b = eng->d_pw_elems * sizeof(double);
     rc = grow((void**)&eng->d_pw, &have_b, (size_t)(3 * n_obs + PLA_AGG_COUNT) * sizeof(double));
@@ -695,7 +714,7 @@ static int waic_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_src, 
   }
   for (int64_t r0 = 0; r0 < n_obs; r0 += rows_per_chunk) {
     const int64_t nr = (n_obs - r0 < rows_per_chunk) ? (n_obs - r0) : rows_per_chunk;
-    rc = stage_rows(eng, ll, row_index, r0, nr, stride_obs, esz, row_bytes, s);
+    rc = stage_rows(eng, ll, row_index, r0, nr, stride_obs, esz, row_bytes, s, stride_draw, dtype, rows_per_chunk);
     if (rc) return rc;
     {
       TimedLaunch t(eng, s);

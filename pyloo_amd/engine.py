@@ -56,17 +56,32 @@ class Engine:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     @staticmethod
-    def _as_2d_host(a):
+    def _as_2d_host(a, allow_obs_fastest=False):
         a = np.asarray(a)
         if a.dtype not in (np.float64, np.float32):
             a = a.astype(np.float64)
         if a.ndim != 2:
             raise ValueError("expected a 2-D (n_obs, n_draws) array")
+        if allow_obs_fastest and Engine._host_obs_fastest(a):
+            return a  # a (chain, draw, *obs) buffer viewed as (obs, sample): the library takes it as it is
         if a.shape[1] > 1 and a.strides[1] != a.itemsize:
             a = np.ascontiguousarray(a)
         if a.shape[0] > 1 and (a.strides[0] % a.itemsize != 0 or a.strides[0] < 0):
             a = np.ascontiguousarray(a)
         return a
+
+    @staticmethod
+    def _host_obs_fastest(a):
+        n, s = a.shape
+        return n > 1 and s > 1 and a.strides[0] == a.itemsize and a.strides[1] % a.itemsize == 0 and a.strides[1] >= n * a.itemsize
+
+    @staticmethod
+    def _host_strides(a):
+        """(stride_obs, stride_draw) in elements of a host matrix prepared by :meth:`_as_2d_host`."""
+        n, s = a.shape
+        if Engine._host_obs_fastest(a):
+            return 1, a.strides[1] // a.itemsize
+        return (a.strides[0] // a.itemsize if n > 1 else s), 1
 
     @staticmethod
     def _draws_fastest(t):
@@ -104,9 +119,9 @@ class Engine:
         mcode = METHOD_CODES[method]
         if _is_torch_tensor(ll):
             return self._psis_loo_device(ll, tail_count, mcode, scale_value, good_k, pointwise, aggregate, rows)
-        a = self._as_2d_host(ll)
+        a = self._as_2d_host(ll, allow_obs_fastest=rows is None)
         n, s = a.shape
-        so = a.strides[0] // a.itemsize if n > 1 else s
+        so, sd = self._host_strides(a)
         if rows is not None:
             idx = self._host_rows(rows, n)
             m = idx.size
@@ -122,7 +137,7 @@ class Engine:
         lppd_i = np.empty(n) if pointwise else None
         agg = np.zeros(AGG_COUNT) if aggregate else None
         p = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)  # noqa: E731
-        check(self._lib.pla_psis_loo(self._h, a.ctypes.data_as(C.c_void_p), dtype_code(a.dtype), n, s, so, 1,
+        check(self._lib.pla_psis_loo(self._h, a.ctypes.data_as(C.c_void_p), dtype_code(a.dtype), n, s, so, sd,
                                      mcode, int(tail_count), float(scale_value), float(good_k), PLA_HOST,
                                      None, p(diag), p(loo_i), p(lppd_i), p(agg)))
         return {"diag": diag, "loo_i": loo_i, "lppd_i": lppd_i, "agg": agg}
@@ -227,9 +242,9 @@ class Engine:
             check(self._lib.pla_waic(self._h, C.c_void_p(t.data_ptr()), code, n, s, t.stride(0), t.stride(1),
                                      float(scale_value), PLA_DEVICE, self._stream(), p(lppd_i), p(var_i), p(waic_i), p(agg)))
             return {"lppd_i": lppd_i, "var_i": var_i, "waic_i": waic_i, "agg": agg}
-        a = self._as_2d_host(ll)
+        a = self._as_2d_host(ll, allow_obs_fastest=rows is None)
         n, s = a.shape
-        so = a.strides[0] // a.itemsize if n > 1 else s
+        so, sd = self._host_strides(a)
         idx = None if rows is None else self._host_rows(rows, n)
         m = n if idx is None else idx.size
         lppd_i, var_i, waic_i = (np.empty(m), np.empty(m), np.empty(m)) if pointwise else (None, None, None)
@@ -239,7 +254,7 @@ class Engine:
             check(self._lib.pla_waic_rows(self._h, a.ctypes.data_as(C.c_void_p), dtype_code(a.dtype), n, s, so, 1, p(idx), m,
                                           float(scale_value), PLA_HOST, None, p(lppd_i), p(var_i), p(waic_i), p(agg)))
             return {"lppd_i": lppd_i, "var_i": var_i, "waic_i": waic_i, "agg": agg}
-        check(self._lib.pla_waic(self._h, a.ctypes.data_as(C.c_void_p), dtype_code(a.dtype), n, s, so, 1,
+        check(self._lib.pla_waic(self._h, a.ctypes.data_as(C.c_void_p), dtype_code(a.dtype), n, s, so, sd,
                                  float(scale_value), PLA_HOST, None, p(lppd_i), p(var_i), p(waic_i), p(agg)))
         return {"lppd_i": lppd_i, "var_i": var_i, "waic_i": waic_i, "agg": agg}
 

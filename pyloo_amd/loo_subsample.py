@@ -200,10 +200,16 @@ def loo_subsample_from_matrix(log_likelihood, observations=100, loo_approximatio
     M = tail_count_for(n_samples, reff)
     if M + 1 > n_samples:
         raise IndexError(f"index {-M - 1} is out of bounds for axis 0 with size {n_samples}")
-    res = eng.psis_loo(log_likelihood, M, ISMethod.PSIS.value, scale_value, good_k, aggregate=False, rows=indices.idx)
+    if _is_torch_tensor(log_likelihood):  # resident matrix: the sampled rows are read in place
+        res = eng.psis_loo(log_likelihood, M, ISMethod.PSIS.value, scale_value, good_k, aggregate=False, rows=indices.idx)
+        var_m = eng.waic(log_likelihood, 1.0, aggregate=False, rows=indices.idx)["var_i"]
+    else:  # host matrix (possibly an observations-fastest view): only the m sampled rows travel
+        sub = np.ascontiguousarray(np.asarray(log_likelihood)[indices.idx])
+        res = eng.psis_loo(sub, M, ISMethod.PSIS.value, scale_value, good_k, aggregate=False)
+        var_m = eng.waic(sub, 1.0, aggregate=False)["var_i"]
     loo_m = _to_host(res["loo_i"]).astype(np.float64)
     khat = _to_host(res["diag"]).astype(np.float64)
-    p_loo_m = _to_host(eng.waic(log_likelihood, 1.0, aggregate=False, rows=indices.idx)["var_i"]).astype(np.float64)
+    p_loo_m = _to_host(var_m).astype(np.float64)
 
     if est == "hh_pps":
         z = compute_sampling_probabilities(approx)[indices.idx]

@@ -5,6 +5,7 @@ Tolerance: north_star asks for 1e-6 relative on fp64 inputs; the engine is held 
 below (three orders tighter) with an absolute floor ATOL for quantities that pass through 0."""
 
 import os
+import warnings
 
 import numpy as np
 import pytest
@@ -570,6 +571,33 @@ def test_observation_fastest_ingestion(eng, N, S, dt):
         np.testing.assert_array_equal(wa[key].cpu().numpy(), wb[key].cpu().numpy(), err_msg=key)
     sub = eng.psis_loo(view, M, "psis", 1.0, 0.7, rows=np.array([N - 1, 0]))   # (row selection on such a view: copied first)
     np.testing.assert_array_equal(sub["loo_i"].cpu().numpy(), b["loo_i"].cpu().numpy()[[N - 1, 0]])
+
+
+@pytest.mark.parametrize("N,S,dt", [(300, 4000, np.float64), (65, 1000, np.float32), (2, 256, np.float64)])
+def test_host_observation_fastest_view(eng, N, S, dt):
+    """A (chain, draw, obs) host array viewed as (obs, sample) -- what stack_samples() hands on -- goes up as pitched slabs
+    and is transposed on the device: same bits as the host-transposed copy, no copy made on the host."""
+    rng = np.random.default_rng(N * S)
+    native = (-rng.uniform(0.1, 0.9, size=(1, 1, N)) * rng.exponential(size=(4, S // 4, N)) - 0.5).astype(dt)  # (chain, draw, obs)
+    view = native.reshape(S, N).T
+    assert view.base is not None and view.strides == (native.itemsize, N * native.itemsize)
+    copy = np.ascontiguousarray(view)
+    M = orc.tail_count(S, 1.0)
+    a, b = eng.psis_loo(view, M, "psis", 1.0, 0.7), eng.psis_loo(copy, M, "psis", 1.0, 0.7)
+    for key in ("diag", "loo_i", "lppd_i", "agg"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    wa, wb = eng.waic(view, 1.0), eng.waic(copy, 1.0)
+    for key in ("lppd_i", "var_i", "waic_i", "agg"):
+        np.testing.assert_array_equal(wa[key], wb[key], err_msg=key)
+    import pyloo_amd as pl
+    from pyloo_amd.utils import stack_samples
+
+    m, _, _, _ = stack_samples(native)
+    assert m.strides == view.strides and np.shares_memory(m, native)       # the front hands the view on
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = pl.loo(native, reff=1.0, pointwise=True)
+    np.testing.assert_array_equal(np.asarray(out["loo_i"]).ravel(), b["loo_i"])
 
 
 @pytest.mark.parametrize("N", [1, 2, 3, 5, 63, 65])
