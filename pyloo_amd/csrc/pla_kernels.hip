@@ -222,6 +222,17 @@ static int debug_flag(const char* name) {
   return v ? atoi(v) : 0;
 }
 
+// Workgroups of a wave-per-row kernel with `waves` waves per workgroup: 512 workgroups are resident (2 per CU), so the grid is
+// 512 x 2^k -- whole rounds -- with k as large as leaves every wave >= 24 rows (a wave's first row is loaded without overlap:
+// short-lived waves pay that start-up again and again), at most 8 rounds (many rounds even out clock and memory-channel luck)
+static int64_t wave_grid(int64_t n_obs, int waves) {
+  const int64_t need = (n_obs + waves - 1) / waves;
+  if (need <= 512) return need < 1 ? 1 : need;
+  int64_t grid = 512;
+  while (grid < 4096 && n_obs / (2 * grid * waves) >= 24) grid *= 2;
+  return grid;
+}
+
 template <typename T, int VEC, bool LW>
 static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, hipStream_t stream, hipEvent_t after_first, bool* recorded) {
   hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
@@ -235,8 +246,7 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, hipStream_t 
   FastParams f{gsz, kq, p.slow_list, p.counters, dbg, p.l1_table, std::log((double)p.n_draws), p.l1_table + p.tail_count, mestM};
   // 4 independent waves per workgroup (they share the read-only tables); 8 x 2048 waves keep all
   // 256 CUs (8 waves each) busy with a short tail
-  int64_t grid = (p.n_obs + kWavesPerBlock - 1) / kWavesPerBlock;
-  if (grid > 2048 * 8 / kWavesPerBlock) grid = 2048 * 8 / kWavesPerBlock;
+  const int64_t grid = wave_grid(p.n_obs, kWavesPerBlock);
   const bool split = !LW && !fused && !dbg && p.ws_y && p.ws_s && mestM <= kFitGrid && p.ws_stride % 64 == 0 && p.ws_stride <= 256 &&
                      p.tail_count <= p.ws_stride;
   if constexpr (!LW) {
