@@ -845,7 +845,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     const double lo0 = -ngs, spread = m - lo0;
     const int ki = (int)((gs - lo0) * (1048576.0 * recip_fast(spread)));  // spread = 0 (constant sample): t1 = 0 -> general kernel
     int lo_i = 0, hi_i = 1 << 20;
-#pragma unroll 1
+#pragma unroll
     for (int it = 0; it < PLA_BISECT_ITERS; ++it) {  // 2^-iters of the spread of the group maxima: a handful of candidates
       const int mid = (lo_i + hi_i) >> 1;
       const int below = __popcll(__ballot(ki < mid));
