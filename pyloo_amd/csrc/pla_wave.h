@@ -308,11 +308,15 @@ __device__ __forceinline__ void issue_row_loads(T (&v)[kWaveSlots], const T* rp,
   }
 }
 
-// one 16-byte vector (slots q*VEC .. q*VEC+VEC-1) of a row
-template <typename T, int VEC>
-__device__ __forceinline__ void issue_row_vector(T (&v)[kWaveSlots], const __amdgpu_buffer_rsrc_t rs, int q) {
+// one 16-byte vector (slots q*VEC .. q*VEC+VEC-1) of a row.  `sbase4k` (optional): a scalar register holding
+// 4096 * (q / 4), so that four consecutive vectors share one scalar offset and differ in the instruction's immediate
+// (0, 1024, 2048, 3072) instead of costing an s_movk each
+template <typename T, int VEC, bool SHARED_BASE = false>
+__device__ __forceinline__ void issue_row_vector(T (&v)[kWaveSlots], const __amdgpu_buffer_rsrc_t rs, int q, int sbase4k = 0) {
   typedef int v4i __attribute__((ext_vector_type(4)));
-  const v4i t = __builtin_amdgcn_raw_buffer_load_b128(rs, wave_lane() * 16, q * (kWave * 16), PLA_LOAD_AUX);
+  v4i t;
+  if constexpr (SHARED_BASE) t = __builtin_amdgcn_raw_buffer_load_b128(rs, wave_lane() * 16 + (q & 3) * (kWave * 16), sbase4k, PLA_LOAD_AUX);
+  else t = __builtin_amdgcn_raw_buffer_load_b128(rs, wave_lane() * 16, q * (kWave * 16), PLA_LOAD_AUX);
   if constexpr (VEC == 2) {
     v[2 * q] = (T)__hiloint2double(t[1], t[0]);
     v[2 * q + 1] = (T)__hiloint2double(t[3], t[2]);
@@ -915,6 +919,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     // candidate append) is issued before stage B of draw i (polynomial, accumulate), so the LDS
     // latency of the table read is covered by the arithmetic of the draws in between.
     constexpr int kPF = PLA_SWEEP_DEPTH;
+    int sbase = 0;  // scalar part of the next row's load offsets
     double px[kPF], pt[kPF];
     int4 ptt[kPF];
 #pragma unroll
@@ -965,7 +970,15 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         // row's vector is streamed into the same registers: the loads of row r+1 trickle out during
         // the sweep of row r and have the whole selection / fit / smoothing phase to arrive, without a
         // single extra register and without a burst that would stall every wave of the CU at once.
-        if ((i % VEC) == VEC - 1) issue_row_vector<T, VEC>(v, rs_next, i / VEC);
+        if ((i % VEC) == VEC - 1) {
+          constexpr int kPerBase = 4096 / (kWave * 16);  // vectors per 4 KB of row
+          const int q = i / VEC;
+          if (q % kPerBase == 0) {
+            sbase = q * (kWave * 16);
+            asm volatile("" : "+s"(sbase));  // one scalar per four vectors (the compiler would materialise one per load)
+          }
+          issue_row_vector<T, VEC, true>(v, rs_next, q, sbase);
+        }
       }
     }
     const unsigned ncand = (next8 - cand0) >> 3;
