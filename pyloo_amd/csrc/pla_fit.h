@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kWave * kFitWaves, 2) void fit_rows_kernel(FitParam
     const double at = row_all(acc_t, op_sum), ar = row_all(acc_r, op_sum);
     // ---- outputs (loo.py:289,319-337 through the shortcuts of DESIGN.md section 4) --------------------------
     const double total = smoothed ? s1 + at : s1;
-    bool bad_out = !(total > 0.01 * s1);  // the tail cancels against the sum of all exponentials
+    bool bad_out = !(total > kCancelGuard * s1);  // the tail cancels against the sum of all exponentials
     const double tail_ratio = smoothed ? (double)(S - n) + ar : (double)S;
     const double lg = log_tab(t == 1 ? s2 : div_fast(tail_ratio, total), lt);
     const double lg1 = dpp_mov_u<0xB1, 0xF>(lg);  // lane t = 0 receives lane 1's logarithm

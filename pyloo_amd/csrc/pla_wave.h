@@ -40,7 +40,15 @@
 #define PLA_ROW_INLINE __forceinline__
 #endif
 
+// total = (sum_all e^x - sum_tail e^x) + sum_tail w' cancels when the raw tail dominates the row; the sweep's exponentials
+// carry up to 1.5e-13 relative (dropped r^4 term) that the tail's full-precision ones do not, so the result keeps
+// ~1.5e-13 / guard: rows below the guard are left to the general kernel, which sums like the reference
+#ifndef PLA_CANCEL_GUARD
+#define PLA_CANCEL_GUARD 0.002
+#endif
 namespace pla {
+
+constexpr double kCancelGuard = PLA_CANCEL_GUARD;
 
 #ifndef PLA_WAVE_SLOTS
 #define PLA_WAVE_SLOTS 64
@@ -724,7 +732,7 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
     if constexpr (LW) wave_all2<R_SUM>(s1, acc_t, s1_all, at_all);  // (acc_t is 0 in every lane when nothing was smoothed)
     else wave_all4<R_SUM>(s1, acc_t, s2, acc_r, s1_all, at_all, s2_all, ar_all);
     const double total = s1_all + at_all;
-    if (!(total > 0.01 * s1_all)) slow = true;
+    if (!(total > kCancelGuard * s1_all)) slow = true;
     if constexpr (LW) {
       // ---- weights mode: lw_s = x_s - log(total) for every draw, the smoothed tail at its positions ----
       const double L = log_tab(total, tb.lt);  // psis.py:158 (_logsumexp of the shifted, smoothed row)

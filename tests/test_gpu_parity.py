@@ -645,3 +645,18 @@ def test_fit_kernel_branches(eng, S, reff):
     close(res["loo_i"], ref["loo_i"], what="loo_i")
     close(res["lppd_i"], ref["lppd_i"], what="lppd_i")
     np.testing.assert_allclose(res["agg"][1], ref["elpd_loo"], rtol=RTOL)
+
+
+def test_heavy_tails_near_the_cancellation_guard(eng):
+    """k-hat above 1: the raw tail carries most of the row and total = (sum_all - sum_tail) + sum_smoothed cancels by up to
+    the guard (PLA_CANCEL_GUARD) before a row is handed to the general kernel; rows on both sides of it stay within tolerance."""
+    rng = np.random.default_rng(77)
+    N, S = 768, 4000
+    k = rng.uniform(1.0, 1.6, size=(N, 1))
+    ll = -k * rng.exponential(size=(N, S)) + rng.normal(size=(N, 1))
+    ref = orc.loo_arrays(ll, 1.0)
+    res = eng.psis_loo(ll, orc.tail_count(S, 1.0), "psis", 1.0, ref["good_k"])
+    close(res["diag"], ref["khat"], what="khat")
+    close(res["loo_i"], ref["loo_i"], what="loo_i")
+    close(res["lppd_i"], ref["lppd_i"], what="lppd_i")
+    assert 0 < int(res["agg"][7]) < N // 4  # some rows are beyond the guard, most are not
