@@ -19,8 +19,8 @@
  *   - matrices are (n_obs, n_draws) with element strides (stride_obs, stride_draw) in
  *     ELEMENTS.  Two layouts are fast: stride_draw == 1 (draws contiguous), and stride_obs == 1 with
  *     stride_draw >= n_obs (observations contiguous: pyloo's stacked `(*obs, __sample__)` view of an ArviZ
- *     (chain, draw, *obs) array, loo.py:189) -- pla_psis_loo and pla_waic transpose the latter block by block on
- *     the device.  Anything else runs on the strided general kernel (device pointers) or is refused (host pointers).
+ *     (chain, draw, *obs) array, loo.py:189) -- pla_psis_loo, pla_waic and (device pointers) pla_importance_weights
+ *     transpose the latter block by block on the device.  Anything else runs on the strided general kernel (device pointers) or is refused (host pointers).
  *   - an engine is bound to one device; calls on one engine must be serialised by the
  *     caller, different engines are independent (no hidden global state).
  */

@@ -589,6 +589,26 @@ int pla_importance_weights(pla_engine* eng, const void* logw, int dtype, int64_t
   }
 
   if (mem_space == PLA_DEVICE) {
+    if (obs_fastest_device(mem_space, nullptr, n_obs, n_draws, stride_obs, stride_draw)) {
+      // observations-fastest log ratios: transposed block by block like the LOO pass; the weights come out as the
+      // (n_obs, n_draws) C-contiguous matrix the header promises
+      const int64_t rows_per_chunk = staged_chunk_rows(mem_space, true, n_obs, n_draws, esz);
+      rc = grow(&eng->d_in, &eng->d_in_bytes, (size_t)rows_per_chunk * (size_t)n_draws * esz);
+      if (rc) return rc;
+      p.in = eng->d_in;
+      p.stride_obs = n_draws;
+      p.stride_draw = 1;
+      TimedLaunch t(eng, s);
+      for (int64_t r0 = 0; r0 < n_obs; r0 += rows_per_chunk) {
+        const int64_t nr = (n_obs - r0 < rows_per_chunk) ? (n_obs - r0) : rows_per_chunk;
+        PLA_HIP(pla::launch_transpose_rows(logw, dtype, stride_draw, r0, nr, (int)n_draws, eng->d_in, s));
+        p.n_obs = nr;
+        p.diag = diag ? diag + r0 : nullptr;
+        p.lw_out = (char*)lw_out + (size_t)r0 * (size_t)n_draws * esz;
+        PLA_HIP(pla::launch_rows(p, dtype, true, s));
+      }
+      return PLA_OK;
+    }
     p.in = logw;
     p.stride_obs = stride_obs;
     p.stride_draw = stride_draw;

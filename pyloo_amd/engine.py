@@ -86,9 +86,9 @@ class Engine:
     @staticmethod
     def _draws_fastest(t):
         """ArviZ keeps log-likelihoods as (chain, draw, *obs): the (obs, sample) view of such a buffer has the
-        observations fastest.  The LOO and WAIC entry points of the library take that layout as it is (a tiled
-        transpose kernel feeds the row kernels block by block); the weights pass still wants unit stride along the
-        draws, so there such a view is copied first (if the copy does not fit, the strided general kernel takes it)."""
+        observations fastest.  The entry points of the library take that layout as it is (a tiled transpose kernel
+        feeds the row kernels block by block); this copy is only for layouts the library would walk with strides
+        (if the copy does not fit, the strided general kernel takes them)."""
         import torch
 
         if t.dim() == 2 and t.shape[1] > 1 and t.stride(1) != 1:
@@ -100,7 +100,7 @@ class Engine:
 
     @staticmethod
     def _library_layout(t, rows=None):
-        """Layouts the LOO / WAIC passes read fast without a copy: draws fastest, or observations fastest (stride 1 along
+        """Layouts the library reads fast without a copy: draws fastest, or observations fastest (stride 1 along
         the observations, no row selection); anything else goes through :meth:`_draws_fastest`."""
         if t.dim() == 2 and t.shape[0] > 1 and t.shape[1] > 1 and t.stride(0) == 1 and t.stride(1) >= t.shape[0] and rows is None:
             return t
@@ -193,7 +193,7 @@ class Engine:
         if _is_torch_tensor(logw):
             import torch
 
-            t = self._draws_fastest(logw)
+            t = self._library_layout(logw)
             n, s = t.shape
             lw = torch.empty((n, s), dtype=t.dtype, device=t.device)
             diag = torch.empty(n, dtype=torch.float64, device=t.device)
