@@ -660,3 +660,37 @@ def test_heavy_tails_near_the_cancellation_guard(eng):
     close(res["loo_i"], ref["loo_i"], what="loo_i")
     close(res["lppd_i"], ref["lppd_i"], what="lppd_i")
     assert 0 < int(res["agg"][7]) < N // 4  # some rows are beyond the guard, most are not
+
+
+def test_ingestion_in_many_blocks():
+    """The transposing ingestion with 1 MB blocks (32 rows each at S = 4000): block boundaries, output offsets and the
+    hand-over workspace of the split pass sized per block.  Own process: the block size is read once per process."""
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from pyloo_amd.engine import get_engine
+from oracle import psis_oracle as orc
+eng = get_engine(0)
+rng = np.random.default_rng(5)
+N, S = 301, 4000
+ll = -rng.uniform(0.1, 0.9, size=(N, 1)) * rng.exponential(size=(N, S)) - 0.5
+view = torch.from_numpy(np.ascontiguousarray(ll.T)).cuda().T
+a = eng.psis_loo(view, 190, "psis", 1.0, 0.7)
+b = eng.psis_loo(torch.from_numpy(ll).cuda(), 190, "psis", 1.0, 0.7)
+for k in ("diag", "loo_i", "lppd_i", "agg"):
+    assert np.array_equal(a[k].cpu().numpy(), b[k].cpu().numpy()), k
+w1, w2 = eng.waic(view, 1.0), eng.waic(torch.from_numpy(ll).cuda(), 1.0)
+assert np.array_equal(w1["waic_i"].cpu().numpy(), w2["waic_i"].cpu().numpy())
+lw1, k1 = eng.importance_weights(-view, 190, "psis")
+lw2, k2 = eng.importance_weights(torch.from_numpy(-ll).cuda(), 190, "psis")
+assert np.array_equal(lw1.cpu().numpy(), lw2.cpu().numpy()) and np.array_equal(k1.cpu().numpy(), k2.cpu().numpy())
+h1 = eng.psis_loo(np.ascontiguousarray(ll.T).T, 190, "psis", 1.0, 0.7)   # host view, observations fastest
+assert np.array_equal(h1["loo_i"], b["loo_i"].cpu().numpy())
+print("blocks ok")
+""" % ROOT
+    env = dict(os.environ, PLA_INGEST_BLOCK_MB="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "blocks ok" in out.stdout, out.stdout + out.stderr
