@@ -21,8 +21,16 @@
  *     stride_draw >= n_obs (observations contiguous: pyloo's stacked `(*obs, __sample__)` view of an ArviZ
  *     (chain, draw, *obs) array, loo.py:189) -- pla_psis_loo, pla_waic and (device pointers) pla_importance_weights
  *     transpose the latter block by block on the device.  Anything else runs on the strided general kernel (device pointers) or is refused (host pointers).
- *   - an engine is bound to one device; calls on one engine must be serialised by the
- *     caller, different engines are independent (no hidden global state).
+ *   - threads and streams: an engine is bound to one device and owns ONE workspace.  Every entry point that takes an
+ *     engine holds the engine's mutex for the whole call, so concurrent calls from several threads are safe (they run one
+ *     after the other); different engines are independent (no hidden global state).  PLA_DEVICE calls only ENQUEUE work
+ *     that uses the workspace: issue them on ONE stream per engine (or order the streams yourself) -- two streams running
+ *     passes of the same engine side by side would share its scratch buffers.  Growing the workspace frees the old buffers
+ *     with hipFree, which waits for the device, so launches already enqueued are never left with dangling pointers.
+ *   - HIP graphs: a captured PLA_DEVICE call holds raw workspace pointers.  Size the workspace first (one eager call
+ *     of the largest shape and tail count to be replayed), then pla_engine_set_frozen(eng, 1): from then on a call that
+ *     would have to reallocate returns PLA_ERR_FROZEN instead of invalidating the graph.  The per-tail-count quantile
+ *     tables are immutable once created, so eager calls with other tail counts do not disturb a captured graph.
  */
 #ifndef PYLOO_AMD_H
 #define PYLOO_AMD_H
@@ -33,7 +41,7 @@
 extern "C" {
 #endif
 
-#define PLA_ABI_VERSION 1
+#define PLA_ABI_VERSION 2
 
 /* status codes */
 #define PLA_OK 0
@@ -42,6 +50,7 @@ extern "C" {
 #define PLA_ERR_NOMEM (-3)       /* device or host allocation failed */
 #define PLA_ERR_UNSUPPORTED (-4) /* shape outside what the kernels support */
 #define PLA_ERR_NODEVICE (-5)    /* no usable AMD GPU */
+#define PLA_ERR_FROZEN (-6)      /* the call needs to (re)allocate engine workspace while the engine is frozen */
 
 /* element type of the log-likelihood / log-weight matrix */
 #define PLA_F64 0
@@ -77,6 +86,10 @@ int pla_device_count(int *count);
  * the PLA_DEVICE path, so calls can be captured in a hipGraph). */
 int pla_engine_create(int device, pla_engine **out);
 int pla_engine_destroy(pla_engine *eng);
+
+/* frozen != 0: the workspace may no longer be reallocated (see "HIP graphs" above); 0 lifts it.  The reference has no
+ * counterpart (it allocates per call: psis.py:92, base.py:125). */
+int pla_engine_set_frozen(pla_engine *eng, int frozen);
 
 /* M of base.py:139-141 / psis.py:89:  ceil(min(S/5, 3*sqrt(S/reff)));  cutoff_ind = -M-1 */
 int pla_tail_count(int64_t n_draws, double reff, int64_t *tail_count);

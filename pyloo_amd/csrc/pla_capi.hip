@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -42,6 +43,12 @@ int pow2_at_least(int64_t n) {
 
 struct pla_engine {
   int device = 0;
+  // One engine = one workspace: every entry point that takes an engine holds this lock for the whole call, so
+  // concurrent callers (ctypes releases the GIL) are serialised instead of racing on the buffers below.
+  std::mutex mu;
+  // frozen: the workspace may be referenced by a captured HIP graph; a call that would have to reallocate any of
+  // it returns PLA_ERR_FROZEN instead (pla_engine_set_frozen)
+  bool frozen = false;
   unsigned long long* counters = nullptr;  // [4] device
   double* d_red = nullptr;                 // reduction partials
   // staging for PLA_HOST callers (grown on demand)
@@ -53,15 +60,16 @@ struct pla_engine {
   size_t d_pw_elems = 0;
   void* d_slow = nullptr;  // [n] row list of the fast path
   size_t d_slow_bytes = 0;
-  double* d_l1 = nullptr;  // log1p(-(j+0.5)/M), j < M, for the current tail count
+  // quantile tables log1p(-(j+0.5)/M), one immutable device buffer per tail count M seen so far (never rewritten
+  // or freed before the engine is destroyed: enqueued launches and captured graphs keep valid pointers)
+  struct L1Table { int64_t M; double* d; };
+  std::vector<L1Table> l1_tables;
   void* d_ws = nullptr;    // hand-over buffers of the split LOO pass: [n][stride] tail values + [n][8] scalars
   size_t d_ws_bytes = 0;
   void* d_rows = nullptr;  // clamped copy of a caller's device row-index list
   void* d_slab = nullptr;  // host path, observations-fastest input: (n_draws, block of observations) slab before the transpose
   size_t d_slab_bytes = 0;
   size_t d_rows_bytes = 0;
-  size_t d_l1_bytes = 0;
-  int64_t l1_M = -1;
   // timing of the main kernel
   bool timing = false;
   static constexpr int kTimingRing = 64;  // launches timed without a host-side wait in between
@@ -76,8 +84,14 @@ struct pla_engine {
 
 namespace {
 
+thread_local bool g_frozen = false;  // set from the engine at the start of every entry point (EngineCall)
+
 int grow(void** p, size_t* have, size_t want) {
   if (*have >= want) return PLA_OK;
+  if (g_frozen)
+    return fail(PLA_ERR_FROZEN, "the engine workspace is frozen (pla_engine_set_frozen) and this call needs %zu more bytes of it",
+                want - *have);
+  // hipFree waits for the device: launches already enqueued on any stream have finished with the old buffer
   if (*p) (void)hipFree(*p);
   *p = nullptr;
   *have = 0;
@@ -112,12 +126,16 @@ int check_common(pla_engine* eng, const void* in, int dtype, int64_t n_obs, int6
 // Row-independent tables of the fast path, computed with the host libm exactly as NumPy does:
 //   [0, M)      log1p(-(j + 0.5)/M)              psis.py:153 through log1p of psis.py:219/221
 //   [M, M+64)   1 - sqrt(m_est / (j + 0.5))      psis.py:186 for m_est = 30 + isqrt(M)
-int ensure_l1_table(pla_engine* e, int64_t M, hipStream_t s) {
-  if (e->l1_M == M && e->d_l1) return PLA_OK;
-  void* p = e->d_l1;
-  int rc = grow(&p, &e->d_l1_bytes, (size_t)(M + 64) * sizeof(double));
-  e->d_l1 = (double*)p;
-  if (rc) return rc;
+int ensure_l1_table(pla_engine* e, int64_t M, hipStream_t s, const double** out) {
+  for (const auto& t : e->l1_tables)
+    if (t.M == M) {
+      *out = t.d;
+      return PLA_OK;
+    }
+  if (g_frozen) return fail(PLA_ERR_FROZEN, "the engine is frozen and has no quantile table for tail_count %lld", (long long)M);
+  double* d = nullptr;
+  hipError_t he = hipMalloc((void**)&d, (size_t)(M + 64) * sizeof(double));
+  if (he != hipSuccess) return fail(PLA_ERR_NOMEM, "hipMalloc(table): %s", hipGetErrorString(he));
   std::vector<double> h((size_t)M + 64);
   for (int64_t j = 0; j < M; ++j) h[(size_t)j] = std::log1p(-(((double)j + 0.5) / (double)M));
   int64_t root = (int64_t)std::sqrt((double)M);
@@ -125,12 +143,23 @@ int ensure_l1_table(pla_engine* e, int64_t M, hipStream_t s) {
   while ((root + 1) * (root + 1) <= M) ++root;
   const double mest = (double)(30 + root);
   for (int j = 0; j < 64; ++j) h[(size_t)M + j] = 1.0 - std::sqrt(mest / ((double)(j + 1) - 0.5));
-  hipError_t he = hipMemcpyAsync(e->d_l1, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, s);
+  he = hipMemcpyAsync(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, s);
   if (he == hipSuccess) he = hipStreamSynchronize(s);  // h goes out of scope
-  if (he != hipSuccess) return fail(PLA_ERR_HIP, "table upload: %s", hipGetErrorString(he));
-  e->l1_M = M;
+  if (he != hipSuccess) {
+    (void)hipFree(d);
+    return fail(PLA_ERR_HIP, "table upload: %s", hipGetErrorString(he));
+  }
+  e->l1_tables.push_back({M, d});
+  *out = d;
   return PLA_OK;
 }
+
+// every entry point: serialise on the engine and publish its frozen flag to grow()
+struct EngineCall {
+  std::lock_guard<std::mutex> lock;
+  explicit EngineCall(pla_engine* e) : lock(e->mu) { g_frozen = e->frozen; }
+  ~EngineCall() { g_frozen = false; }
+};
 
 struct TimedLaunch {  // brackets the main kernel with events when timing is on
   pla_engine* e;
@@ -138,6 +167,7 @@ struct TimedLaunch {  // brackets the main kernel with events when timing is on
   TimedLaunch(pla_engine* e_, hipStream_t s_) : e(e_), s(s_) {
     if (e->timing) {
       if (e->pending == pla_engine::kTimingRing) flush(e);  // the only case in which the host waits
+      e->has_mid[e->pending] = false;  // (a reused ring slot must not inherit the mid event of an earlier split pass)
       (void)hipEventRecord(e->ev0[e->pending], s);
     }
   }
@@ -224,7 +254,7 @@ int pla_engine_destroy(pla_engine* e) {
   if (e->d_lw) (void)hipFree(e->d_lw);
   if (e->d_pw) (void)hipFree(e->d_pw);
   if (e->d_slow) (void)hipFree(e->d_slow);
-  if (e->d_l1) (void)hipFree(e->d_l1);
+  for (auto& t : e->l1_tables) (void)hipFree(t.d);
   if (e->d_ws) (void)hipFree(e->d_ws);
   if (e->d_rows) (void)hipFree(e->d_rows);
   if (e->d_slab) (void)hipFree(e->d_slab);
@@ -246,8 +276,16 @@ int pla_tail_count(int64_t n_draws, double reff, int64_t* tail_count) {
   return PLA_OK;
 }
 
+int pla_engine_set_frozen(pla_engine* e, int frozen) {
+  if (!e) return fail(PLA_ERR_ARG, "engine is NULL");
+  EngineCall call(e);
+  e->frozen = frozen != 0;
+  return PLA_OK;
+}
+
 int pla_engine_set_timing(pla_engine* e, int enable) {
   if (!e) return fail(PLA_ERR_ARG, "engine is NULL");
+  EngineCall call(e);
   TimedLaunch::flush(e);
   e->timing = enable != 0;
   return PLA_OK;
@@ -255,6 +293,7 @@ int pla_engine_set_timing(pla_engine* e, int enable) {
 
 int pla_engine_kernel_ms(pla_engine* e, double* total_ms, int64_t* launches) {
   if (!e) return fail(PLA_ERR_ARG, "engine is NULL");
+  EngineCall call(e);
   TimedLaunch::flush(e);
   if (total_ms) *total_ms = e->acc_ms;
   if (launches) *launches = e->launches;
@@ -265,6 +304,7 @@ int pla_engine_kernel_ms(pla_engine* e, double* total_ms, int64_t* launches) {
 
 int pla_engine_first_kernel_ms(pla_engine* e, double* total_ms, int64_t* launches) {
   if (!e) return fail(PLA_ERR_ARG, "engine is NULL");
+  EngineCall call(e);
   TimedLaunch::flush(e);
   if (total_ms) *total_ms = e->acc_first_ms;
   if (launches) *launches = e->first_launches;
@@ -279,6 +319,7 @@ int pla_reduce_pointwise(pla_engine* eng, const double* diag, const double* loo_
   if (!agg) return fail(PLA_ERR_ARG, "agg is NULL");
   if (n_obs < 0) return fail(PLA_ERR_ARG, "n_obs < 0");
   if (mem_space != PLA_HOST && mem_space != PLA_DEVICE) return fail(PLA_ERR_ARG, "bad mem_space");
+  EngineCall call(eng);
   PLA_HIP(hipSetDevice(eng->device));
   hipStream_t s = (hipStream_t)stream;
   if (mem_space == PLA_DEVICE) {
@@ -382,6 +423,7 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
     rc = check_rows(row_index, n_obs, n_src, mem_space);
     if (rc) return rc;
   }
+  EngineCall call(eng);
   PLA_HIP(hipSetDevice(eng->device));
   hipStream_t s = (hipStream_t)stream;
   const size_t esz = dtype == PLA_F64 ? 8 : 4;
@@ -401,9 +443,8 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
     if (rc) return rc;
     p.slow_list = (unsigned*)eng->d_slow;
     if (method == PLA_PSIS) {
-      rc = ensure_l1_table(eng, tail_count, s);
+      rc = ensure_l1_table(eng, tail_count, s, &p.l1_table);
       if (rc) return rc;
-      p.l1_table = eng->d_l1;
       // hand-over buffers of the split pass (one-chunk wave kernel -> fit kernel, pla_fit.h): sized for the
       // rows one launch processes (all of them on the device path, one staging chunk on the host path)
       if (tail_count <= 250 && n_draws >= 256 && n_draws <= 4096) {  // (the shapes the one-chunk wave kernel takes)
@@ -564,6 +605,7 @@ int pla_importance_weights(pla_engine* eng, const void* logw, int dtype, int64_t
   int rc = check_common(eng, logw, dtype, n_obs, n_draws, stride_obs, stride_draw, method, tail_count, mem_space);
   if (rc) return rc;
   if (n_obs > 0 && !lw_out) return fail(PLA_ERR_ARG, "lw_out is NULL");
+  EngineCall call(eng);
   PLA_HIP(hipSetDevice(eng->device));
   hipStream_t s = (hipStream_t)stream;
   const size_t esz = dtype == PLA_F64 ? 8 : 4;
@@ -582,9 +624,8 @@ int pla_importance_weights(pla_engine* eng, const void* logw, int dtype, int64_t
     if (rc) return rc;
     p.slow_list = (unsigned*)eng->d_slow;
     if (method == PLA_PSIS) {
-      rc = ensure_l1_table(eng, tail_count, s);
+      rc = ensure_l1_table(eng, tail_count, s, &p.l1_table);
       if (rc) return rc;
-      p.l1_table = eng->d_l1;
     }
   }
 
@@ -668,6 +709,7 @@ static int waic_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_src, 
     rc = check_rows(row_index, n_obs, n_src, mem_space);
     if (rc) return rc;
   }
+  EngineCall call(eng);
   PLA_HIP(hipSetDevice(eng->device));
   hipStream_t s = (hipStream_t)stream;
   const size_t esz = dtype == PLA_F64 ? 8 : 4;
@@ -778,6 +820,7 @@ int pla_fill_synthetic(pla_engine* eng, void* ll_device, int dtype, int64_t n_ob
   if (dtype != PLA_F64 && dtype != PLA_F32) return fail(PLA_ERR_ARG, "dtype must be PLA_F64 or PLA_F32");
   if (n_obs < 0 || n_draws < 1) return fail(PLA_ERR_ARG, "bad shape");
   if (n_obs > 0 && !ll_device) return fail(PLA_ERR_ARG, "ll_device is NULL");
+  EngineCall call(eng);
   PLA_HIP(hipSetDevice(eng->device));
   PLA_HIP(pla::launch_fill_synthetic(ll_device, dtype, n_obs, n_draws, row0, seed, k_lo, k_hi, heavy_lo, heavy_hi,
                                      (hipStream_t)stream));

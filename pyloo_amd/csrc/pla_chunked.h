@@ -36,6 +36,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
   const int M = __builtin_amdgcn_readfirstlane(P.tail_count);
   const int gsz = __builtin_amdgcn_readfirstlane(F.gsz);
   const int kq = __builtin_amdgcn_readfirstlane(F.kq);
+  const int sbits = __builtin_amdgcn_readfirstlane(F.sample_bits);
   constexpr int dbgs = 0;
   const int mestM = __builtin_amdgcn_readfirstlane(F.mest_M);
   const double logS = uniform_d(F.log_S);
@@ -74,24 +75,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
     // ---- pad fix-up (copies of the lane's first vector), max / min of the chunk --------------------
     pad_tail<T, VEC, NQ - 1, false>(v, qfull, qrem, (T)0);
     double mx, mn, gs;
-    {
-      const T ninf = (T)(-INF);
-      T cur = ninf, vmx = ninf, snap = ninf;
-#pragma unroll
-      for (int i = 0; i < EPT; ++i) {
-        cur = vmax_nc<true>(v[i], cur);   // max raw
-        vmx = vmax_nc<false>(v[i], vmx);  // max ll = -min raw
-        if ((i == 3 || i == 7 || i == 15 || i == 31) && i < EPT) {
-          if (gsz == i + 1) {
-            asm volatile("");
-            snap = cur;
-          }
-        }
-      }
-      mx = (double)cur;
-      mn = -(double)vmx;
-      gs = (double)snap;
-    }
+    row_stats<T, VEC, false>(v, gsz, sbits, mx, mn, gs);  // (gs: the threshold sample, used for chunk 0 only)
     double mc, nmnc;
     wave_all2<R_MAX>(mx, -mn, mc, nmnc);  // min = -max(-.)
     const double mnc = -nmnc;

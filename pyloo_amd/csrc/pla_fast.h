@@ -13,6 +13,27 @@ __device__ __forceinline__ double red_apply(double a, double b) {
   else if constexpr (OP == R_MAX) return fmax(a, b);
   else return fmin(a, b);
 }
+// ---- which draws feed the speculative threshold ----------------------------------------------
+// The statistics pass visits the 16-byte vectors of a lane in an order whose first 2^B entries are the bit reversal of
+// 0 .. 2^B - 1 (then the rest in natural order), and the per-lane maximum is snapshotted after the first `gsz` slots: the
+// sample is then spread evenly over the first 2^B vectors of the row -- every chain of a chain-major (chain, draw) stack
+// contributes -- instead of being the row's first draws.  B is the largest of {log2 NQ, log2 NQ - 1, log2 NQ - 2} whose
+// span is mostly real draws, 0 (natural order) for very short rows.
+__host__ __device__ constexpr int bitrev_order(int i, int B) {
+  if (i >= (1 << B)) return i;
+  int r = 0;
+  for (int b = 0; b < B; ++b) r |= ((i >> b) & 1) << (B - 1 - b);
+  return r;
+}
+__host__ __device__ constexpr int sample_bits_for(int qfull, int log_nq) {
+#if defined(PLA_SAMPLE_NATURAL)
+  return 0;  // A/B knob: the row's first draws, as in round 1
+#endif
+  for (int b = log_nq; b >= log_nq - 2 && b > 0; --b)
+    if (3 * (1 << b) <= 4 * qfull) return b;
+  return 0;
+}
+
 struct FastParams {
   int gsz;                        // register slots per lane whose maximum feeds the speculative threshold
   int kq;                         // the threshold has >= kq of the 64 per-lane maxima below it
@@ -24,6 +45,7 @@ struct FastParams {
   const double* b_grid;           // [64] 1 - sqrt(m_est/(j+0.5)) for m_est = mest_M (psis.py:186)
   int mest_M;                     // 30 + isqrt(M)
   // split pass (pla_fit.h): hand-over buffers of the wave kernel, null when the pass is fused
+  int sample_bits = 0;            // B of bitrev_order: which slots the first `gsz` visited ones are
   double* ws_y = nullptr;         // [n_obs][ws_stride] ascending tail values
   double* ws_s = nullptr;         // [n_obs][8] scalars
   int ws_stride = 0;

@@ -196,7 +196,7 @@ static hipError_t launch_one(const RowsParams& p, hipStream_t stream) {
 // F^gsz = kq/64.  Pick (gsz, kq) so that ~2.2(M+1) draws lie above, with kq large enough for the order
 // statistic to be stable.  Returns false when no setting fits (the general kernel takes the call).
 // `cand_cap`: capacity of the LDS candidate list; only the first min(S, 4096) draws feed the maxima.
-static bool wave_threshold_params(int S, int vec, int M, int* gsz_out, int* kq_out, int cand_cap = kCandCap) {
+static bool wave_threshold_params(int S, int vec, int M, int* gsz_out, int* kq_out, int* bits_out, int cand_cap = kCandCap) {
 #ifndef PLA_CAND_MULT
 #define PLA_CAND_MULT 2.2
 #endif
@@ -204,16 +204,24 @@ static bool wave_threshold_params(int S, int vec, int M, int* gsz_out, int* kq_o
   if (target > 0.62 * cand_cap || target >= 0.5 * S) return false;
   const double F = 1.0 - target / S;
   const int S0 = S < kWave * kWaveSlots ? S : kWave * kWaveSlots;
-  const int valid = (S0 / vec / kWave) * vec;  // slots that are real draws in every lane
+  const int qfull = S0 / vec / kWave;  // vectors that are real draws in every lane
+  const int nq = kWaveSlots / vec;
+  const int bits = sample_bits_for(qfull, nq == 32 ? 5 : 4);
   int best_g = 0, best_k = 0;
   for (int g = 4; g <= 32; g <<= 1) {
-    if (g > valid) break;
-    const int k = (int)std::lround(kWave * std::pow(F, g));
+    // the first g slots in visiting order are the vectors bitrev_order(j, bits), j < g / vec; those past the row are pads
+    // (copies of the lane's first vector), so the group maximum is effectively over g_eff slots
+    int g_eff = 0;
+    for (int j = 0; j < (g + vec - 1) / vec; ++j)
+      if (bitrev_order(j, bits) < qfull) g_eff += (g < vec ? g : vec);
+    if (g_eff < 2) continue;
+    const int k = (int)std::lround(kWave * std::pow(F, g_eff));
     if (k >= 6 && k <= 40 && (best_g == 0 || k > best_k)) { best_g = g; best_k = k; }
   }
   if (!best_g) return false;
   *gsz_out = best_g;
   *kq_out = best_k;
+  *bits_out = bits;
   return true;
 }
 
@@ -234,7 +242,7 @@ static int64_t wave_grid(int64_t n_obs, int waves) {
 }
 
 template <typename T, int VEC, bool LW>
-static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, hipStream_t stream, hipEvent_t after_first, bool* recorded) {
+static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, hipStream_t stream, hipEvent_t after_first, bool* recorded) {
   hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   static const int dbg = debug_flag("PLA_DEBUG_SKIP");
@@ -244,6 +252,7 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, hipStream_t 
   while ((root_ + 1) * (root_ + 1) <= p.tail_count) ++root_;
   const int mestM = 30 + root_;
   FastParams f{gsz, kq, p.slow_list, p.counters, dbg, p.l1_table, std::log((double)p.n_draws), p.l1_table + p.tail_count, mestM};
+  f.sample_bits = bits;
   // 4 independent waves per workgroup (they share the read-only tables); 8 x 2048 waves keep all
   // 256 CUs (8 waves each) busy with a short tail
   const int64_t grid = wave_grid(p.n_obs, kWavesPerBlock);
@@ -291,13 +300,14 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, hipStream_t 
 
 // long rows (chunks of 4096 draws) and / or tail counts up to 512: pla_chunked.h
 template <typename T, int VEC, class CAP>
-static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, hipStream_t stream) {
+static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, int bits, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   int root_ = (int)std::sqrt((double)p.tail_count);
   while (root_ * root_ > p.tail_count) --root_;
   while ((root_ + 1) * (root_ + 1) <= p.tail_count) ++root_;
   FastParams f{gsz, kq, p.slow_list, p.counters, 0, p.l1_table, std::log((double)p.n_draws), p.l1_table + p.tail_count, 30 + root_};
+  f.sample_bits = bits;
   constexpr int W = CAP::kWaves;  // waves per workgroup; two workgroups per CU (LDS)
   int64_t grid = (p.n_obs + W - 1) / W;
   if (grid > 2048 * 8 / W) grid = 2048 * 8 / W;
@@ -344,9 +354,9 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream, hipEvent
     if (path != 1 && unit && waligned && p.method == PLA_PSIS && p.slow_list && p.counters && p.l1_table &&
         p.n_draws <= kWave * kWaveSlots && p.n_draws >= 256 && p.tail_count <= kWaveMaxTail &&
         smem_bytes(BLOCK, p.tail_cap) <= 64 * 1024 && p.n_obs <= 0xffffffffll) {
-      int gsz = 0, kq = 0;
-      if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq)) {
-        return launch_wave<T, WVEC, LW>(p, gsz, kq, stream, after_first, recorded);
+      int gsz = 0, kq = 0, bits = 0;
+      if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits)) {
+        return launch_wave<T, WVEC, LW>(p, gsz, kq, bits, stream, after_first, recorded);
       }
     }
     if constexpr (!LW) {
@@ -358,13 +368,13 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream, hipEvent
       if (path != 1 && unit && waligned && p.method == PLA_PSIS && p.slow_list && p.counters && p.l1_table &&
           p.n_draws >= 256 && p.n_draws <= (1 << 20) && last_chunk >= kWave * WVEC && p.tail_count <= CapsBig::kMaxTail &&
           smem_bytes(BLOCK, p.tail_cap) <= 64 * 1024 && p.n_obs <= 0xffffffffll) {
-        int gsz = 0, kq = 0;
-        if (p.tail_count <= CapsMid4::kMaxTail && wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, CapsMid4::kCand))
-          return launch_chunked<T, WVEC, CapsMid4>(p, gsz, kq, stream);
-        if (p.tail_count <= CapsMid::kMaxTail && wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, CapsMid::kCand))
-          return launch_chunked<T, WVEC, CapsMid>(p, gsz, kq, stream);
-        if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, CapsBig::kCand))
-          return launch_chunked<T, WVEC, CapsBig>(p, gsz, kq, stream);
+        int gsz = 0, kq = 0, bits = 0;
+        if (p.tail_count <= CapsMid4::kMaxTail && wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, CapsMid4::kCand))
+          return launch_chunked<T, WVEC, CapsMid4>(p, gsz, kq, bits, stream);
+        if (p.tail_count <= CapsMid::kMaxTail && wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, CapsMid::kCand))
+          return launch_chunked<T, WVEC, CapsMid>(p, gsz, kq, bits, stream);
+        if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, CapsBig::kCand))
+          return launch_chunked<T, WVEC, CapsBig>(p, gsz, kq, bits, stream);
       }
     }
     if (path == 1) return launch_one<T, BLOCK, 0, LW>(p, stream);

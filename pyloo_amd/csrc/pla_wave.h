@@ -351,6 +351,44 @@ __device__ __forceinline__ void pad_tail(T (&v)[kWaveSlots], int qfull, int qrem
   }
 }
 
+
+// Per-lane maximum and minimum of raw (= -v in LOO mode, v in weights mode) over the 64 slots, and the maximum over the first
+// `gsz` slots in visiting order (the threshold sample).  The order is a compile-time permutation of the vectors
+// (bitrev_order over 2^B of them); `bits` picks among the instantiations with a wave-uniform branch, so the pass stays
+// two VALU operations per slot.
+template <typename T, int VEC, bool LW, int B>
+__device__ __forceinline__ void row_stats_b(const T (&v)[kWaveSlots], const int gsz, double& mx, double& mn, double& gs) {
+  // two accumulators per quantity: a dependent fp64 VALU pair needs a wait state the compiler fills with s_nop when the
+  // chain is only two instructions long; four interleaved chains need none
+  const T ninf = (T)(-pinf());
+  T cur[2] = {ninf, ninf}, vmx[2] = {LW ? (T)pinf() : ninf, LW ? (T)pinf() : ninf}, snap = ninf;
+#pragma unroll
+  for (int i = 0; i < kWaveSlots; ++i) {
+    const int sl = bitrev_order(i / VEC, B) * VEC + i % VEC;
+    cur[i & 1] = vmax_nc<!LW>(v[sl], cur[i & 1]);                                   // max raw
+    vmx[i & 1] = LW ? vmin_nc(v[sl], vmx[i & 1]) : vmax_nc<false>(v[sl], vmx[i & 1]);  // min raw (LOO: as max ll)
+    if (i == 3 || i == 7 || i == 15 || i == 31) {  // gsz is one of 4, 8, 16, 32 (wave_threshold_params)
+      if (gsz == i + 1) {
+        asm volatile("");  // a real wave-uniform branch, not a select per slot
+        snap = vmax_nc<false>(cur[0], cur[1]);
+      }
+    }
+  }
+  mx = (double)vmax_nc<false>(cur[0], cur[1]);
+  const T vm = LW ? vmin_nc(vmx[0], vmx[1]) : vmax_nc<false>(vmx[0], vmx[1]);
+  mn = LW ? (double)vm : -(double)vm;
+  gs = (double)snap;
+}
+template <typename T, int VEC, bool LW>
+__device__ __forceinline__ void row_stats(const T (&v)[kWaveSlots], const int gsz, const int bits, double& mx, double& mn, double& gs) {
+  constexpr int NQ = kWaveSlots / VEC;
+  constexpr int L = NQ == 32 ? 5 : (NQ == 16 ? 4 : 3);
+  if (bits == L) row_stats_b<T, VEC, LW, L>(v, gsz, mx, mn, gs);
+  else if (bits == L - 1) row_stats_b<T, VEC, LW, L - 1>(v, gsz, mx, mn, gs);
+  else if (bits == L - 2) row_stats_b<T, VEC, LW, L - 2>(v, gsz, mx, mn, gs);
+  else row_stats_b<T, VEC, LW, 0>(v, gsz, mx, mn, gs);
+}
+
 // Everything after the sweep: exact selection of the M+1 largest among the candidates, GPD fit,
 // smoothing sums and the outputs.  Shared by the one-chunk and the chunked front ends; `lppd_shift` is
 // the log of the factor by which the chunked front's s2 is short (0 otherwise).
@@ -822,26 +860,10 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     pad_tail<T, VEC, NQ - 1, false>(v, qfull, qrem, (T)0);
   }
   // ---- 1. row statistics, in the input precision (exact; duplicates of valid draws are harmless) ---
-  // raw = -ll:  max raw = max(-v),  min raw = -max(v);  gs = max raw over this lane's first `gsz` slots
+  // raw = -ll:  max raw = max(-v),  min raw = -max(v);  gs = max raw over the first `gsz` slots this lane VISITS (a sample
+  // spread over the row, see bitrev_order)
   double mx, mn, gs;
-  {
-    const T ninf = (T)(-INF);
-    T cur = ninf, vmx = LW ? (T)INF : ninf, snap = ninf;
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      cur = vmax_nc<!LW>(v[i], cur);                            // max raw
-      vmx = LW ? vmin_nc(v[i], vmx) : vmax_nc<false>(v[i], vmx);  // min raw (LOO: as max ll)
-      if ((i == 3 || i == 7 || i == 15 || i == 31) && i < EPT) {  // gsz is one of 4, 8, 16, 32 (wave_threshold_params)
-        if (gsz == i + 1) {
-          asm volatile("");  // a real wave-uniform branch, not a select per slot
-          snap = cur;
-        }
-      }
-    }
-    mx = (double)cur;
-    mn = LW ? (double)vmx : -(double)vmx;
-    gs = (double)snap;
-  }
+  row_stats<T, VEC, LW>(v, gsz, __builtin_amdgcn_readfirstlane(F.sample_bits), mx, mn, gs);
   double m, nmn, ngs, unused_;
   wave_all4<R_MAX>(mx, -mn, -gs, -gs, m, nmn, ngs, unused_);  // min = -max(-.): row max, row min, smallest group maximum
   mn = -nmn;

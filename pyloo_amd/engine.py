@@ -285,6 +285,11 @@ class Engine:
         check(self._lib.pla_fill_synthetic(self._h, C.c_void_p(t.data_ptr()), code, n, s, int(row0), int(seed),
                                            k_lo, k_hi, heavy_lo, heavy_hi, self._stream()))
 
+    def set_frozen(self, on):
+        """Frozen: calls that would reallocate engine workspace fail (EngineError -6) instead of invalidating the
+        raw pointers a captured HIP graph holds (include/pyloo_amd.h, "HIP graphs")."""
+        check(self._lib.pla_engine_set_frozen(self._h, 1 if on else 0))
+
     def set_timing(self, on):
         check(self._lib.pla_engine_set_timing(self._h, 1 if on else 0))
 

@@ -51,13 +51,39 @@ def merge_moment_rows(table):
     return out
 
 
-def all_reduce_aggregates(agg, group=None):
+def merge_moment_rows_tensor(table):
+    """:func:`merge_moment_rows` on a torch tensor (any device), without a host round trip: the pooled form
+    ``M2 = sum M2_r + sum n_r (mean_r - mean)^2`` of the same update (a sum of non-negative terms)."""
+    import torch
+
+    n_r = table[:, AGG_N]
+    n = n_r.sum()
+    safe = torch.where(n_r > 0, n_r, torch.ones_like(n_r))
+    mean_r = table[:, AGG_SUM_LOO] / safe
+    mean = table[:, AGG_SUM_LOO].sum() / torch.clamp(n, min=1.0)
+    out = torch.zeros(AGG_COUNT, dtype=table.dtype, device=table.device)
+    out[AGG_N] = n
+    out[AGG_SUM_LOO] = table[:, AGG_SUM_LOO].sum()
+    out[AGG_M2_LOO] = table[:, AGG_M2_LOO].sum() + (n_r * (mean_r - mean) ** 2).sum()
+    out[AGG_SUM_LPPD] = table[:, AGG_SUM_LPPD].sum()
+    out[AGG_N_HIGH] = table[:, AGG_N_HIGH].sum()
+    out[AGG_N_NONFINITE] = table[:, AGG_N_NONFINITE].sum()
+    out[AGG_N_SLOW] = table[:, AGG_N_SLOW].sum()
+    inf = torch.full_like(n_r, float("inf"))
+    out[AGG_MIN_DIAG] = torch.where(n_r > 0, table[:, AGG_MIN_DIAG], inf).min()
+    return out
+
+
+def all_reduce_aggregates(agg, group=None, as_tensor=False):
     """``agg``: this rank's aggregate vector (CUDA tensor, CPU tensor or ndarray).
-    Returns the merged aggregate vector as a NumPy array, identical on every rank."""
+    Returns the merged aggregate vector, identical on every rank: a NumPy array, or with ``as_tensor`` a
+    tensor on the device the collective ran on (RCCL: the GPU; nothing synchronises with the host)."""
     import torch
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()):
+        if as_tensor and hasattr(agg, "detach"):
+            return merge_moment_rows_tensor(agg.detach().reshape(1, AGG_COUNT))
         a = agg.detach().cpu().numpy() if hasattr(agg, "detach") else np.asarray(agg)
         return merge_moment_rows(a[None, :])
     world = dist.get_world_size(group)
@@ -68,4 +94,6 @@ def all_reduce_aggregates(agg, group=None):
     table = torch.zeros((world, AGG_COUNT), dtype=torch.float64, device=where)
     table[rank] = t.to(device=where, dtype=torch.float64)
     dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)  # the single collective
+    if as_tensor:
+        return merge_moment_rows_tensor(table)
     return merge_moment_rows(table.cpu().numpy())

@@ -1,0 +1,150 @@
+"""BASELINE.json configurations at their full per-GPU sizes (``-m gpu``), device-generated with the SURVEY section 8(d)
+generator: C3 (1 M x 4000 f64, the configuration the metric is quoted on; also the per-GPU shard of C4) and one C5 shard
+(125 000 x 20 000 f32, 30 % heavy-tailed rows).  The oracle finishes a strided sample in seconds; the whole matrix is
+covered by size-independent properties (bitwise determinism, the reductions against ``math.fsum``, loo_i <= lppd_i).
+
+Also: the multi-rank flow of ``bench.py --gpus N`` through its own launcher (two ranks on one card over gloo -- RCCL
+refuses two ranks on one device) and the RCCL collective itself at world size 1."""
+
+import json
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import psis_oracle as orc
+from test_gpu_parity import close
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from pyloo_amd.engine import get_engine
+
+    return get_engine(0)
+
+
+def _check_whole_matrix(eng, t, M, good_k, n_sample, slow_bound, heavy_fraction=None):
+    import torch
+
+    N, S = t.shape
+    a = eng.psis_loo(t, M, "psis", 1.0, good_k)
+    b = eng.psis_loo(t, M, "psis", 1.0, good_k)
+    torch.cuda.synchronize()
+    for key in ("diag", "loo_i", "lppd_i", "agg"):
+        assert torch.equal(a[key], b[key]), key  # bitwise reproducible
+    del b
+    loo_i, lppd_i, diag = (a[k].cpu().numpy() for k in ("loo_i", "lppd_i", "diag"))
+    agg = a["agg"].cpu().numpy()
+    assert np.all(np.isfinite(loo_i)) and np.all(np.isfinite(lppd_i)) and np.all(np.isfinite(diag))
+    assert np.all(loo_i <= lppd_i + 1e-9)
+    np.testing.assert_allclose(agg[1], math.fsum(loo_i), rtol=1e-12)
+    np.testing.assert_allclose(agg[3], math.fsum(lppd_i), rtol=1e-12)
+    np.testing.assert_allclose(agg[2] / N, np.var(loo_i), rtol=1e-9)
+    assert agg[0] == N and agg[4] == np.sum(diag > good_k)
+    assert agg[7] <= slow_bound * N, (agg[7], N)  # rows that left the fast selection path
+    if heavy_fraction is not None:
+        assert abs(agg[4] / N - heavy_fraction) < 0.03, agg[4] / N
+    idx = np.arange(0, N, max(1, N // n_sample))[:n_sample]
+    rows = t[torch.from_numpy(idx).to(t.device)].cpu().numpy().astype(np.float64)  # f32 input: parity vs the upcast data
+    ref = orc.loo_arrays(rows, 1.0)
+    close(diag[idx], ref["khat"], what="khat sample")
+    close(loo_i[idx], ref["loo_i"], what="loo_i sample")
+    close(lppd_i[idx], ref["lppd_i"], what="lppd_i sample")
+    return agg
+
+
+def test_c3_full_size(eng):
+    """C3 = C4's per-GPU shard: S=4000 x N=1 000 000 f64 (32 GB), seed 0x5EED0003, 1 000 rows against the oracle."""
+    import torch
+
+    S, N = 4000, 1_000_000
+    t = torch.empty((N, S), dtype=torch.float64, device="cuda")
+    eng.fill_synthetic(t, seed=0x5EED0003)
+    agg = _check_whole_matrix(eng, t, orc.tail_count(S, 1.0), 0.7, 1000, 0.0005)
+    assert agg[5] == 0
+    del t
+    torch.cuda.empty_cache()
+
+
+def test_c5_shard(eng):
+    """One GPU's shard of C5: S=20 000 x N=125 000 f32 (10 GB), seed 0x5EED0005, rows with i mod 10 in {0, 3, 6} drawn
+    with k in [1, 1.3): ~30 % of the observations end above khat = 0.7.  500 rows against the oracle on the upcast data."""
+    import torch
+
+    S, N = 20000, 125_000
+    t = torch.empty((N, S), dtype=torch.float32, device="cuda")
+    eng.fill_synthetic(t, seed=0x5EED0005, k_lo=0.05, k_hi=0.5, heavy_lo=1.0, heavy_hi=1.3)
+    M = orc.tail_count(S, 1.0)
+    assert M == 425
+    # heavy rows whose raw tail cancels against the sum of all exponentials go to the general kernel
+    _check_whole_matrix(eng, t, M, 0.7, 500, 0.005, heavy_fraction=0.30)
+    del t
+    torch.cuda.empty_cache()
+
+
+def _run_bench(args, env_extra, timeout=600):
+    env = dict(os.environ, **env_extra)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_launches_two_ranks(eng):
+    """`python bench.py --gpus 2` (no launcher around it) brings up two ranks itself, shards the observations, merges the
+    aggregates with the one all-reduce and prints ONE line from rank 0.  On a one-GPU box both ranks share the card and
+    reduce over gloo; the driver's multi-GPU node runs the same code over RCCL."""
+    import torch
+
+    n_local, S = 20000, 4000
+    out = _run_bench(["--gpus", "2", "--obs", str(n_local), "--steps", "2", "--warmup", "1", "--no-cpu"],
+                     {"PYLOO_AMD_BENCH_BACKEND": "gloo", "PYLOO_AMD_BENCH_DEVICE": "0"})
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["backend"] == "gloo" and out["scaling"] == "weak"
+    assert out["value"] > 0 and abs(out["value"] - 2 * n_local * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    t = torch.empty((2 * n_local, S), dtype=torch.float64, device="cuda")
+    eng.fill_synthetic(t, seed=0x5EED0003)  # rank r generated rows [r n_local, (r + 1) n_local) of this matrix
+    agg = eng.psis_loo(t, 190, "psis", 1.0, 0.7, pointwise=False)["agg"].cpu().numpy()
+    np.testing.assert_allclose(out["config"]["elpd_loo"], agg[1], rtol=1e-12)
+    assert out["config"]["n_high_k"] == agg[4]
+
+
+def test_rccl_all_reduce_world_size_one():
+    """The RCCL path of the sharded reduction (init_process_group("nccl", device_id=...), device-side table, all_reduce,
+    device-side merge) in a child process; one rank is all a one-GPU box allows RCCL."""
+    code = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from pyloo_amd.engine import get_engine
+from pyloo_amd.sharded import all_reduce_aggregates
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29617")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+eng = get_engine(0)
+t = torch.empty((5000, 4000), dtype=torch.float64, device=dev)
+eng.fill_synthetic(t, seed=77)
+agg = eng.psis_loo(t, 190, "psis", 1.0, 0.7, pointwise=False)["agg"]
+merged = all_reduce_aggregates(agg, as_tensor=True)
+assert merged.is_cuda
+host = all_reduce_aggregates(agg)
+torch.cuda.synchronize()
+a, m = agg.cpu().numpy(), merged.cpu().numpy()
+np.testing.assert_allclose(m, a, rtol=1e-13)
+np.testing.assert_allclose(host, a, rtol=1e-13)
+dist.destroy_process_group()
+print("rccl ok", a[1])
+""" % ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0 and "rccl ok" in proc.stdout, proc.stdout[-1000:] + proc.stderr[-3000:]

@@ -42,6 +42,57 @@ def test_moment_merge_equals_numpy_var():
     assert out[4] == 3 and out[6] == 0.5
 
 
+def test_tensor_merge_equals_numpy_merge():
+    """The device-side merge used inside the multi-GPU timed loop (no host sync) against the Chan update."""
+    import torch
+
+    from pyloo_amd.sharded import merge_moment_rows_tensor
+
+    rng = np.random.default_rng(10)
+    x = rng.normal(-1e4, 0.1, size=9_000)
+    rows = []
+    for lo, hi in ((0, 0), (0, 3000), (3000, 3001), (3001, 9000)):
+        c = x[lo:hi]
+        rows.append([c.size, c.sum(), np.sum((c - c.mean()) ** 2) if c.size else 0.0, c.sum() * 2, c.size % 7, 1, c.min(), 2] if c.size else [0.0] * 8)
+    table = np.array(rows)
+    want = merge_moment_rows(table)
+    got = merge_moment_rows_tensor(torch.from_numpy(table)).numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-13)
+    np.testing.assert_allclose(got[2] / x.size, np.var(x), rtol=1e-10)
+
+
+def test_bench_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts N ranks through torch.distributed.run on the loopback
+    interface and relays the exit code; the parent never imports torch."""
+    import importlib.util
+    import subprocess
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 7
+
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    before = "torch" in sys.modules
+    assert bench.main() == 7
+    assert ("torch" in sys.modules) == before
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ
+
+
 def _worker(rank, world, port, ll, reff, out_q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,10 +1,11 @@
 #!/bin/bash
 # PMC passes for the LOO kernel (separate rocprofv3 runs; no trace domains combined with --pmc)
 set -e
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc
+OUT=$ROOT/gpurun_out/pmc
 mkdir -p $OUT
-ARGS="$GRAFT_REPO_ROOT/bench.py --obs ${OBS:-200000} --steps 2 --warmup 1 --no-cpu"
+ARGS="$ROOT/bench.py --obs ${OBS:-200000} --steps 2 --warmup 1 --no-cpu"
 i=0
 for grp in "$@"; do
   i=$((i+1))
