@@ -178,6 +178,30 @@ int pla_waic_rows(pla_engine *eng, const void *ll, int dtype, int64_t n_obs, int
                   double scale_value, int mem_space, void *stream, double *lppd_i, double *var_i,
                   double *waic_i, double *agg);
 
+/*
+ * pla_e_loo -- PSIS-weighted expectations of a same-shape matrix and their function-specific Pareto k.
+ * Replaces, per observation, e_loo.py:214-236: `_normalize_log_weights` + `_compute_weighted_mean` (430-437, 557-559),
+ * `_compute_weighted_variance` / `_wvar_func` (440-459, 518-531; sd = sqrt(variance), 462-465) and `compute_pareto_k` ->
+ * `k_hat` (266-390) for h = x (mean), h = x^2 (variance / sd) and h = None (quantiles), i.e. the `wrap_xarray_ufunc` loops of
+ * e_loo.py:315-324, 448-457 and the callers on top of psislw: loo_score.py:227,312, loo_predictive_metric.py:208.
+ *
+ *   x            (n_obs, n_draws) draws to average (posterior-predictive or posterior values), const
+ *   log_weights  (n_obs, n_draws) log importance weights, any normalisation (the smoothed weights of
+ *                pla_importance_weights; `weights=` callers pass log(weights), e_loo.py:202-203)
+ *   log_ratios   (n_obs, n_draws) raw log ratios for the diagnostics, or NULL = log_weights (e_loo.py:223-224)
+ *                -- all three share dtype, shape and strides
+ *   tail_len     draws per tail in k_hat (20: e_loo.py:269); >= 5
+ *   mean, variance, k_mean, k_var, k_ratio   [n_obs] double, each may be NULL
+ *                k_mean = k_hat(x, lr), k_var = k_hat(x^2, lr), k_ratio = k_hat(None, lr)
+ * In-band semantics as in the reference: NaN / inf in x flow into mean and variance by IEEE rules and switch k to the
+ * ratio-only value (e_loo.py:359-366); constant x gives variance 0 (520-521).  k_hat is reproduced AS THE REFERENCE EVALUATES
+ * IT, including the descending tails it hands to `_gpdfit` (see csrc/pla_eloo.h for what that implies).
+ */
+int pla_e_loo(pla_engine *eng, const void *x, const void *log_weights, const void *log_ratios, int dtype,
+              int64_t n_obs, int64_t n_draws, int64_t stride_obs, int64_t stride_draw, int64_t tail_len,
+              int mem_space, void *stream, double *mean, double *variance, double *k_mean, double *k_var,
+              double *k_ratio);
+
 /* Timing of the dominant kernel, measured with hipEvents on the launch stream.
  * enable != 0 brackets every main-kernel launch with events; pla_engine_kernel_ms returns the
  * accumulated milliseconds and launch count since the last call (it synchronises the events). */

@@ -2,7 +2,7 @@
 
 This module is a NumPy restatement of the arithmetic of the reference's hot path
 (jordandeklerk/pyloo, ``pyloo/psis.py``, ``pyloo/utils.py:305-359``,
-``pyloo/loo.py:286-342``, ``pyloo/sis.py:86-106``, ``pyloo/tis.py:91-120``).  It exists
+``pyloo/loo.py:286-342``, ``pyloo/sis.py:86-106``, ``pyloo/tis.py:91-120``, ``pyloo/e_loo.py:328-559``).  It exists
 only so that ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
 ``bench.py`` have something to check and time the HIP engine against.  Nothing under
 ``pyloo_amd/`` imports it; the product path has no CPU fallback.
@@ -262,6 +262,121 @@ def waic_arrays(ll, scale_value=1):
         "has_nan": has_nan,
         "has_inf": has_inf,
     }
+
+
+# ---------------------------------------------------------------------------------------------
+# Weighted expectations (e_loo.py) -- SURVEY section 8 f4
+# ---------------------------------------------------------------------------------------------
+def k_hat_row(h, log_ratios, tail_len=20):
+    """Function-specific Pareto k of one observation (e_loo.py:328-390), followed line by line -- INCLUDING the order in
+    which the reference hands the tails to ``_gpdfit``: ``sorted_r - cutoff`` etc. are DESCENDING with a last element of
+    exactly 0, where ``_gpdfit`` expects ascending values; ``1 / ary[-1]`` is then +-inf, every grid weight NaN, none
+    survives ``w >= 10 eps`` and the fit degenerates to ``k = (n * 0 + 5) / (n + 10)`` (1/6 for a 20-draw tail).  That is what
+    the reference returns, so that is what is restated (and what the fixtures of make_golden_e_loo.py hold)."""
+    lr = np.asarray(log_ratios)
+    with np.errstate(all="ignore"):
+        r = np.exp(lr - np.max(lr))                                   # e_loo.py:350
+        top = -np.sort(-r)[:tail_len]                                 # 351
+        if len(top) < 5 or np.allclose(top, top[0]):                  # 353-354
+            k_r = np.inf
+        else:
+            k_r, _ = gpd_fit(top - top[-1])                           # 356-357
+        if (h is None or np.allclose(h, h[0]) or len(np.unique(h)) == 2 or np.any(np.isnan(h))
+                or np.any(np.isinf(h))):                              # 359-366
+            return k_r
+        hr = h * r                                                    # 368
+        left = np.sort(hr)[:tail_len]                                 # 370
+        right = -np.sort(-hr)[:tail_len]                              # 371
+        if len(left) < 5 or np.allclose(left, left[0]):               # 373-377
+            k_left = -np.inf
+        else:
+            k_left, _ = gpd_fit(-(left - left[-1]))
+        if len(right) < 5 or np.allclose(right, right[0]):            # 379-383
+            k_right = -np.inf
+        else:
+            k_right, _ = gpd_fit(right - right[-1])
+        k_hr = max(k_left, k_right)                                   # 385 (Python max: NaN-order dependent, kept)
+        if np.isnan(k_hr) and np.isnan(k_r):                          # 387-388
+            return np.nan
+        return max(k_hr, k_r)                                         # 390
+
+
+def weighted_variance_row(x, w):
+    """e_loo.py:518-531 (``w`` normalised)."""
+    if np.allclose(x, x[0]):
+        return 0.0
+    wss = np.sum(w**2)
+    if np.isclose(wss, 1.0):
+        return 0.0
+    mean = np.sum(w * x)
+    mean_sq = np.sum(w * x**2)
+    return max((mean_sq - mean**2) / (1 - wss), 0.0)
+
+
+def weighted_quantile_row(x, w, prob):
+    """e_loo.py:534-554."""
+    if np.allclose(w, w[0]):
+        return np.quantile(x, prob)
+    order = np.argsort(x)
+    xs, ws = x[order], w[order]
+    ww = np.cumsum(ws) / np.sum(ws)
+    ids = np.where(ww >= prob)[0]
+    if len(ids) == 0:
+        return xs[-1]
+    wi = ids[0]
+    if wi == 0:
+        return xs[0]
+    w1, x1 = ww[wi - 1], xs[wi - 1]
+    return x1 + (xs[wi] - x1) * (prob - w1) / (ww[wi] - w1)
+
+
+def pareto_min_ss(k):
+    """e_loo.py:393-398."""
+    return 10 ** (1 / (1 - max(0, k))) if k < 1 else float("inf")
+
+
+def pareto_khat_threshold(n_samples):
+    """e_loo.py:401-403."""
+    return 1 - 1 / np.log10(n_samples)
+
+
+def pareto_convergence_rate(k, n_samples):
+    """e_loo.py:406-427."""
+    if k < 0:
+        return 1.0
+    if k > 1:
+        return 0.0
+    if k == 0.5:
+        return 1 - 1 / np.log(n_samples)
+    if 0 < k < 1:
+        n = n_samples
+        return max(0, (2 * (k - 1) * n ** (2 * k + 1) + (1 - 2 * k) * n ** (2 * k) + n**2) / ((n - 1) * (n - n ** (2 * k))))
+    return 1.0
+
+
+def e_loo_arrays(x, log_weights, log_ratios=None, probs=None):
+    """``e_loo`` (e_loo.py:56-264) for (N, S) arrays, every ``type`` at once: weighted mean (430-437), variance (440-459),
+    sd (462-465), quantiles for ``probs`` (468-515), and the k of each type (226-236: h = x for the mean, x**2 for variance
+    and sd, None for quantiles; ``log_ratios`` defaults to the log-weights, 223-224)."""
+    x = np.asarray(x)
+    lw = np.asarray(log_weights)
+    lr = lw if log_ratios is None else np.asarray(log_ratios)
+    n, s = x.shape
+    with np.errstate(all="ignore"):
+        nlw = np.stack([row - lse(row) for row in lw])                # 557-559, one _logsumexp per row
+        w = np.exp(nlw)
+        out = {
+            "mean": (w * x).sum(axis=-1),
+            "var": np.array([weighted_variance_row(x[i], w[i]) for i in range(n)], dtype=np.float64),
+            "k_mean": np.array([k_hat_row(x[i], lr[i]) for i in range(n)], dtype=np.float64),
+            "k_var": np.array([k_hat_row(x[i] ** 2, lr[i]) for i in range(n)], dtype=np.float64),
+            "k_none": np.array([k_hat_row(None, lr[i]) for i in range(n)], dtype=np.float64),
+        }
+        out["sd"] = np.sqrt(out["var"])
+        if probs is not None:
+            out["quant"] = np.array([[weighted_quantile_row(x[i], w[i], p) for p in np.atleast_1d(probs)] for i in range(n)],
+                                    dtype=np.float64)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------

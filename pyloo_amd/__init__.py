@@ -3,6 +3,7 @@
 through the C ABI in ``include/pyloo_amd.h``; there is no CPU fallback."""
 
 from .base import ISMethod, compute_importance_weights
+from .e_loo import ExpectationResult, compute_pareto_k, e_loo, k_hat
 from .elpd import ELPDData
 from .loo import loo, loo_from_matrix
 from .loo_i import loo_i
@@ -11,7 +12,7 @@ from .psis import psislw
 from .rcparams import rcParams
 from .waic import waic, waic_from_matrix
 
-__all__ = ["ISMethod", "ELPDData", "compute_importance_weights", "loo", "loo_from_matrix", "loo_i", "loo_subsample",
+__all__ = ["ISMethod", "ELPDData", "ExpectationResult", "compute_importance_weights", "compute_pareto_k", "e_loo", "k_hat", "loo", "loo_from_matrix", "loo_i", "loo_subsample",
            "loo_subsample_from_matrix", "psislw", "rcParams", "waic",
            "waic_from_matrix"]
 __version__ = "0.1.0"

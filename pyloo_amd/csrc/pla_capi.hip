@@ -814,6 +814,61 @@ int pla_waic_rows(pla_engine* eng, const void* ll, int dtype, int64_t n_obs, int
                    lppd_i, var_i, waic_i, agg);
 }
 
+int pla_e_loo(pla_engine* eng, const void* x, const void* log_weights, const void* log_ratios, int dtype, int64_t n_obs,
+              int64_t n_draws, int64_t stride_obs, int64_t stride_draw, int64_t tail_len, int mem_space, void* stream, double* mean,
+              double* variance, double* k_mean, double* k_var, double* k_ratio) {
+  if (!eng) return fail(PLA_ERR_ARG, "engine is NULL");
+  if (dtype != PLA_F64 && dtype != PLA_F32) return fail(PLA_ERR_ARG, "dtype must be PLA_F64 or PLA_F32");
+  if (mem_space != PLA_HOST && mem_space != PLA_DEVICE) return fail(PLA_ERR_ARG, "bad mem_space");
+  if (n_obs < 0) return fail(PLA_ERR_ARG, "n_obs < 0");
+  if (n_obs > 0 && (!x || !log_weights)) return fail(PLA_ERR_ARG, "x / log_weights is NULL");
+  if (n_draws < 1 || n_draws > (int64_t)1 << 30) return fail(PLA_ERR_ARG, "n_draws out of range");
+  if (stride_draw <= 0 || stride_obs < 0) return fail(PLA_ERR_ARG, "bad strides");
+  if (tail_len < 5) return fail(PLA_ERR_ARG, "tail_len must be at least 5");  // e_loo.py:298-299
+  if (n_obs == 0) return PLA_OK;
+  EngineCall call(eng);
+  PLA_HIP(hipSetDevice(eng->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (mem_space == PLA_DEVICE) {
+    PLA_HIP(pla::launch_e_loo(x, log_weights, log_ratios, dtype, n_obs, (int)n_draws, stride_obs, stride_draw, (int)tail_len, mean,
+                              variance, k_mean, k_var, k_ratio, s));
+    return PLA_OK;
+  }
+  // ---- PLA_HOST: row blocks of the two or three matrices through the staging buffers (d_in: x, d_lw: log-weights, d_slab: ratios)
+  if (stride_draw != 1) return fail(PLA_ERR_UNSUPPORTED, "PLA_HOST input needs stride_draw == 1");
+  const size_t esz = dtype == PLA_F64 ? 8 : 4;
+  const size_t row_bytes = (size_t)n_draws * esz;
+  int64_t rows_per_chunk = (int64_t)(((size_t)1 << 29) / row_bytes);
+  if (rows_per_chunk < 1) rows_per_chunk = 1;
+  if (rows_per_chunk > n_obs) rows_per_chunk = n_obs;
+  int rc = grow(&eng->d_in, &eng->d_in_bytes, (size_t)rows_per_chunk * row_bytes);
+  if (!rc) rc = grow(&eng->d_lw, &eng->d_lw_bytes, (size_t)rows_per_chunk * row_bytes);
+  if (!rc && log_ratios) rc = grow(&eng->d_slab, &eng->d_slab_bytes, (size_t)rows_per_chunk * row_bytes);
+  if (rc) return rc;
+  {
+    size_t have_b = eng->d_pw_elems * sizeof(double);
+    rc = grow((void**)&eng->d_pw, &have_b, (size_t)(5 * rows_per_chunk) * sizeof(double));
+    eng->d_pw_elems = have_b / sizeof(double);
+    if (rc) return rc;
+  }
+  double* out[5] = {mean, variance, k_mean, k_var, k_ratio};
+  for (int64_t r0 = 0; r0 < n_obs; r0 += rows_per_chunk) {
+    const int64_t nr = (n_obs - r0 < rows_per_chunk) ? (n_obs - r0) : rows_per_chunk;
+    const size_t off = (size_t)r0 * stride_obs * esz, pitch = (size_t)stride_obs * esz;
+    PLA_HIP(hipMemcpy2DAsync(eng->d_in, row_bytes, (const char*)x + off, pitch, row_bytes, (size_t)nr, hipMemcpyHostToDevice, s));
+    PLA_HIP(hipMemcpy2DAsync(eng->d_lw, row_bytes, (const char*)log_weights + off, pitch, row_bytes, (size_t)nr, hipMemcpyHostToDevice, s));
+    if (log_ratios)
+      PLA_HIP(hipMemcpy2DAsync(eng->d_slab, row_bytes, (const char*)log_ratios + off, pitch, row_bytes, (size_t)nr, hipMemcpyHostToDevice, s));
+    double* d = eng->d_pw;
+    PLA_HIP(pla::launch_e_loo(eng->d_in, eng->d_lw, log_ratios ? eng->d_slab : nullptr, dtype, nr, (int)n_draws, n_draws, 1, (int)tail_len,
+                              d, d + nr, d + 2 * nr, d + 3 * nr, d + 4 * nr, s));
+    for (int k = 0; k < 5; ++k)
+      if (out[k]) PLA_HIP(hipMemcpyAsync(out[k] + r0, d + k * nr, (size_t)nr * sizeof(double), hipMemcpyDeviceToHost, s));
+    PLA_HIP(hipStreamSynchronize(s));  // the staging buffers are reused by the next block
+  }
+  return PLA_OK;
+}
+
 int pla_fill_synthetic(pla_engine* eng, void* ll_device, int dtype, int64_t n_obs, int64_t n_draws, int64_t row0,
                        uint64_t seed, double k_lo, double k_hi, double heavy_lo, double heavy_hi, void* stream) {
   if (!eng) return fail(PLA_ERR_ARG, "engine is NULL");

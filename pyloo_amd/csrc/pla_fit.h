@@ -7,6 +7,12 @@
 // and hands over, per observation, the ascending tail values y_j (psis.py:146-147) and six scalars; this
 // kernel gives every DPP row of 16 lanes one observation (four observations per wavefront):
 //   * the tail sits in the registers of its 16 lanes (4 NQ values each, one coalesced read);
+//   * (PLA_FIT_SORTS, the default) the wave kernel hands the tail over only GROUPED BY BIN of its selection histogram, bins
+//     descending; the order inside the bins (a handful of values each) is finished here: the values are brought to a blocked
+//     layout through LDS (lane t holds the descending ranks 4 NQ t .. 4 NQ t + 4 NQ - 1) and a few odd-even transposition
+//     passes -- register min / max pairs, one DPP exchange per lane boundary -- run until every row of the wave is sorted
+//     (checked, so any order, even a fully unsorted one, ends sorted).  That is ~35 issue slots per observation against
+//     the ~420 the exact in-bin ranking costs the wave kernel, where 64 lanes serve one observation;
 //   * the Zhang-Stephens grid (psis.py:163-208) is three grid points b_j per lane; the factors
 //     prod_i (1 - b_j y_i) are taken four y at a time as a quartic in the grid coordinate whose five
 //     coefficients each lane builds for its own quads and every lane of the row reads back from LDS
@@ -85,7 +91,18 @@ __global__ __launch_bounds__(kWave * kFitWaves, 2) void fit_rows_kernel(FitParam
   const int M = Q.tail_count, S = Q.n_draws, mestM = Q.mest_M;
   for (int j = tid; j < kTabN; j += kWave * kFitWaves) exp_table_entry(tab, j);
   for (int j = tid; j < kLogTabN; j += kWave * kFitWaves) log_table_entry(lt, j);
-  for (int j = tid; j < 64 * NQ; j += kWave * kFitWaves) l1s[j] = Q.l1_table[j < M ? j : M - 1];
+  if constexpr (kFitSorts) {
+    // the register layout of the sorted tail: lane t holds the DESCENDING ranks p = K t + i (K = 4 NQ), i.e. the reference's
+    // ascending index j = n - 1 - p.  The quantile table is stored reversed (for the usual n == M) and in the order the lanes
+    // read it: entry (i / 2) * 32 + 2 t + (i & 1) belongs to p = K t + i  (conflict-free 16-byte reads).
+    for (int idx = tid; idx < 64 * NQ; idx += kWave * kFitWaves) {
+      const int p = (4 * NQ) * ((idx & 31) >> 1) + 2 * (idx >> 5) + (idx & 1);
+      const int j = M - 1 - p;
+      l1s[idx] = Q.l1_table[j < 0 ? 0 : j];
+    }
+  } else {
+    for (int j = tid; j < 64 * NQ; j += kWave * kFitWaves) l1s[j] = Q.l1_table[j < M ? j : M - 1];
+  }
   __syncthreads();
   const double INF = pinf();
   const auto op_sum = [](double a, double b) { return a + b; };
@@ -95,6 +112,7 @@ __global__ __launch_bounds__(kWave * kFitWaves, 2) void fit_rows_kernel(FitParam
   const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
 #if PLA_FIT_MFMA
   double* ck = coef + (size_t)wv * (5 * 4 * QN);
+  double* ys_base = ck;  // (sorting scratch: 4 x 64 NQ doubles of this wave's coefficient area, which is written afterwards)
   // One MFMA evaluates 4 quads x 4 observations x 16 grid points: D[row][col] = C0 + sum_k A[row][k] B[k][col] with
   // tile row = observation + 4 * quad (so the four results a lane receives, rows rho + 4 i at column t, are four
   // quads of the lane's OWN observation at its own grid point), A[row][k] = C_(k+1) of that quad and
@@ -110,7 +128,9 @@ __global__ __launch_bounds__(kWave * kFitWaves, 2) void fit_rows_kernel(FitParam
   }
 #else
   double* cf_row = coef + (size_t)((wv * 4 + rho) * 16 * NQ) * kFitCoefStride;
+  double* ys_base = coef + (size_t)(wv * 4 * 16 * NQ) * kFitCoefStride;
 #endif
+  (void)ys_base;
   // grid coordinates of this lane: j = t, t + 16, t + 32
   double g[3];
   bool gact[3];
@@ -139,7 +159,59 @@ __global__ __launch_bounds__(kWave * kFitWaves, 2) void fit_rows_kernel(FitParam
 #pragma unroll
     for (int i = 0; i < 2 * NQ; ++i) yv[i] = *reinterpret_cast<const double2*>(y + 32 * i + 2 * t);
     const int iq = ((n + 2) >> 2) - 1;
-    const double yq = y[iq > 0 ? iq : 0], yn = y[n > 0 ? n - 1 : 0];
+    double yq, yn;
+    if constexpr (kFitSorts) {
+      constexpr int K = 4 * NQ;
+      // interleaved (as loaded) -> blocked, through this wave's LDS scratch (the coefficient area: written later)
+      double* ys = ys_base + rho * (64 * NQ);
+#pragma unroll
+      for (int i = 0; i < 2 * NQ; ++i) *reinterpret_cast<double2*>(ys + 32 * i + 2 * t) = yv[i];
+      wave_sync();
+#pragma unroll
+      for (int i = 0; i < 2 * NQ; ++i) {
+        yv[i] = *reinterpret_cast<const double2*>(ys + K * t + 2 * i);
+        if (!fit) yv[i] = make_double2(0.0, 0.0);  // (nothing was handed over: whatever the buffer held must not reach the sort)
+      }
+      // descending odd-even transposition sort of the row's 16 K values: yb(i) = rank K t + i
+      const auto yb = [&](int i) -> double& { return (i & 1) ? yv[i >> 1].y : yv[i >> 1].x; };
+      const auto ce = [&](double& hi, double& lo) {
+        const double a = vmax_nc<false>(hi, lo), b = vmin_nc(hi, lo);
+        hi = a;
+        lo = b;
+      };
+      const auto sort_round = [&]() {
+#pragma unroll
+        for (int i = 0; i < K; i += 2) ce(yb(i), yb(i + 1));
+#pragma unroll
+        for (int i = 1; i < K - 1; i += 2) ce(yb(i), yb(i + 1));
+        // the pair that straddles two lanes: rank K t + K - 1 (this lane) and K (t + 1) (the next lane's first)
+        const double right0 = dpp_mov<0x101, 0xF>(yb(0), -INF);     // row_shl:1; lane 15 of the row: nothing to its right
+        const double leftk = dpp_mov<0x111, 0xF>(yb(K - 1), INF);   // row_shr:1; lane 0: nothing to its left
+        yb(K - 1) = vmax_nc<false>(yb(K - 1), right0);
+        yb(0) = vmin_nc(yb(0), leftk);
+      };
+      const auto unsorted = [&]() {
+        bool u = yb(K - 1) < dpp_mov<0x101, 0xF>(yb(0), -INF);
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i) u = u || (yb(i) < yb(i + 1));
+        return __ballot(u) != 0ull;
+      };
+      // bins of the selection histogram hold <= 8 values in all but a few per cent of the rows: four rounds (eight passes)
+      // finish those; the check keeps going for the rest (16 K passes sort ANY order, the cap is that bound)
+#pragma unroll 1
+      for (int it = 0; it < 4; ++it) sort_round();
+#pragma unroll 1
+      for (int it = 0; it < 8 * K && unsorted(); ++it) sort_round();
+#pragma unroll
+      for (int i = 0; i < 2 * NQ; ++i) *reinterpret_cast<double2*>(ys + K * t + 2 * i) = yv[i];
+      wave_sync();
+      const int pq = n - 1 - (iq > 0 ? iq : 0);
+      yq = ys[pq > 0 ? pq : 0];  // psis.py:187: ascending element int(n/4 + 0.5) - 1
+      yn = ys[0];                // psis.py:188: the largest
+    } else {
+      yq = y[iq > 0 ? iq : 0];
+      yn = y[n > 0 ? n - 1 : 0];
+    }
     const double R = m - mn;
     const double nn = (double)n, rn = recip_fast(nn);
     bool bad = (30 + isqrt_i(n)) != mestM;  // (ties shortened the tail a lot: the host grid table does not apply)
@@ -310,7 +382,22 @@ __global__ __launch_bounds__(kWave * kFitWaves, 2) void fit_rows_kernel(FitParam
     };
     // (the sums are pinned every few elements: left alone, the scheduler starts every element at once and spills)
     const auto pin = [&]() { asm volatile("" : "+v"(acc_t), "+v"(acc_r)); };
-    if (__ballot(fit && n != M) == 0ull) {
+    if constexpr (kFitSorts) {
+      constexpr int K = 4 * NQ;
+      const bool usual = __ballot(fit && n != M) == 0ull;
+#pragma unroll
+      for (int i = 0; i < 2 * NQ; ++i) {
+        const int p = K * t + 2 * i;  // descending rank of yv[i].x; the reference's ascending index is n - 1 - p (psis.py:146,153)
+        double2 l1 = *reinterpret_cast<const double2*>(l1s + 32 * i + 2 * t);
+        if (!usual) {  // ties shortened some tail of this wave: p_j = (j + 0.5)/n with the observation's own n
+          asm volatile("");
+          if (n != M) l1 = make_double2(log_fast(1.0 - ((double)(n - 1 - p) + 0.5) * rn), log_fast(1.0 - ((double)(n - 2 - p) + 0.5) * rn));
+        }
+        smooth(p, l1.x, yv[i].x);
+        smooth(p + 1, l1.y, yv[i].y);
+        if ((i % PLA_FIT_PIN) == PLA_FIT_PIN - 1) pin();
+      }
+    } else if (__ballot(fit && n != M) == 0ull) {
       // the usual case, straight-line: log1p(-p_j) from the host table (psis.py:153)
 #pragma unroll
       for (int i = 0; i < 2 * NQ; ++i) {

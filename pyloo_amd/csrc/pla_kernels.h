@@ -66,6 +66,10 @@ hipError_t launch_fill_synthetic(void* ll, int dtype, int64_t n_obs, int64_t n_d
 hipError_t launch_waic(const void* in, const int64_t* row_index, int dtype, int64_t n_obs, int n_draws, int64_t stride_obs, int64_t stride_draw,
                        double scale_value, double* lppd_i, double* var_i, double* waic_i,
                        unsigned long long* replaced, hipStream_t stream);
+// weighted expectations + function-specific Pareto k (e_loo.py:56-264): x, lw, lr share dtype, shape and strides; lr may equal lw
+hipError_t launch_e_loo(const void* x, const void* lw, const void* lr, int dtype, int64_t n_obs, int n_draws, int64_t stride_obs,
+                        int64_t stride_draw, int tail_len, double* mean, double* var, double* k_mean, double* k_var, double* k_none,
+                        hipStream_t stream);
 // largest tail count the kernels accept
 int max_tail_count();
 

@@ -22,6 +22,7 @@
 #include "pla_chunked.h"
 #include "pla_is.h"
 #include "pla_fit.h"
+#include "pla_eloo.h"
 
 namespace pla {
 
@@ -475,6 +476,17 @@ hipError_t launch_waic(const void* in, const int64_t* row_index, int dtype, int6
   if (n_obs <= 0) return hipSuccess;
   WaicParams p{in, n_obs, n_draws, stride_obs, stride_draw, scale_value, lppd_i, var_i, waic_i, replaced, row_index};
   return dtype == PLA_F64 ? launch_waic_typed<double>(p, stream) : launch_waic_typed<float>(p, stream);
+}
+
+hipError_t launch_e_loo(const void* x, const void* lw, const void* lr, int dtype, int64_t n_obs, int n_draws, int64_t stride_obs,
+                        int64_t stride_draw, int tail_len, double* mean, double* var, double* k_mean, double* k_var, double* k_none,
+                        hipStream_t stream) {
+  if (n_obs <= 0) return hipSuccess;
+  ELooParams p{x, lw, lr ? lr : lw, n_obs, n_draws, stride_obs, stride_draw, tail_len, mean, var, k_mean, k_var, k_none};
+  const int64_t grid = n_obs < 16384 ? n_obs : 16384;
+  if (dtype == PLA_F64) hipLaunchKernelGGL((e_loo_rows_kernel<double, 256>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((e_loo_rows_kernel<float, 256>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+  return hipGetLastError();
 }
 
 int reduce_workspace_doubles() { return kRedChunks * kRedSlots; }

@@ -49,6 +49,12 @@
 namespace pla {
 
 constexpr double kCancelGuard = PLA_CANCEL_GUARD;
+// split pass: 1 = the wave kernel hands the tail over grouped by bin and the fit kernel finishes the order (pla_fit.h);
+// 0 = the wave kernel ranks the tail itself and hands it over ascending (round 1; kept for A/B runs)
+#ifndef PLA_FIT_SORTS
+#define PLA_FIT_SORTS 1
+#endif
+constexpr bool kFitSorts = PLA_FIT_SORTS != 0;
 
 #ifndef PLA_WAVE_SLOTS
 #define PLA_WAVE_SLOTS 64
@@ -387,6 +393,10 @@ __device__ __forceinline__ void row_stats(const T (&v)[kWaveSlots], const int gs
   else if (bits == L - 1) row_stats_b<T, VEC, LW, L - 1>(v, gsz, mx, mn, gs);
   else if (bits == L - 2) row_stats_b<T, VEC, LW, L - 2>(v, gsz, mx, mn, gs);
   else row_stats_b<T, VEC, LW, 0>(v, gsz, mx, mn, gs);
+  // every row load has landed by now (each order ends on the last vector).  Said explicitly, because the compiler's
+  // wait-count bookkeeping loses track across the merge of the four variants and would otherwise guard every later
+  // read of the row with a (satisfied, but issued) s_waitcnt vmcnt.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
 }
 
 // Everything after the sweep: exact selection of the M+1 largest among the candidates, GPD fit,
@@ -427,7 +437,7 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
   }
   wave_sync();
   PLA_PHASE(5);
-  int bstar = 0, C1 = 0;
+  int bstar = 0, C1 = 0, nbnd = 0;  // boundary bin, candidates at/above it, candidates IN it
   {
     unsigned c[8];
     unsigned tot = 0;
@@ -449,7 +459,7 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
     const unsigned all = (unsigned)__builtin_amdgcn_readlane((int)pre, kWave - 1);
     const unsigned suf = all - pre + tot;  // this lane's bins and everything above
     unsigned a = suf - tot;  // candidates in bins owned by higher lanes
-    int fb = -1, fc = 0;
+    int fb = -1, fc = 0, fn = 0;
     unsigned st[8];
 #pragma unroll
     for (int i = 7; i >= 0; --i) {
@@ -457,6 +467,7 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
       if ((unsigned)M >= a && (unsigned)M < a + c[i]) {
         fb = 8 * lane + i;
         fc = (int)(a + c[i]);
+        fn = (int)c[i];
       }
       a += c[i];
     }
@@ -466,6 +477,7 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
     const int src = __ffsll((long long)who) - 1;
     bstar = __builtin_amdgcn_readlane(fb, src);
     C1 = __builtin_amdgcn_readlane(fc, src);
+    nbnd = __builtin_amdgcn_readlane(fn, src);
   }
   wave_sync();
   if (C1 > kSa) {
@@ -501,6 +513,56 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
           if constexpr (LW) sm.sa_id[slot] = idv[u];
         }
       }
+    }
+    if constexpr (SPLIT && kFitSorts) {
+      // ---- split pass: hand the tail over to the fit kernel (pla_fit.h: 16 lanes per observation) -----------------
+      // The candidates are grouped by bin, bins descending, and that is how they go: the fit kernel finishes the order
+      // inside its 16-lane rows with a few odd-even transposition passes (bins hold a handful of values), which costs a
+      // tenth of ranking them here with 64 lanes per observation.  Only the boundary bin is resolved now: it holds the
+      // cutoff x_(S-M) itself (psis.py:135-136) and decides which of its members belong to the tail (strictly above it,
+      // psis.py:139: ties at the cutoff leave the tail).
+      wave_sync();
+      PLA_PHASE(8);
+      const int na = C1 - nbnd;  // candidates in the bins above the boundary bin: all of them are in the tail
+      if (nbnd > kWave) {
+        slow = true;  // (more than 64 draws share the cutoff's bin: heavy ties)
+      } else {
+        const double xb = sm.sa[na + (lane < nbnd ? lane : 0)];
+        int gt = 0, ge = 0;
+        for (int j = 0; j < nbnd; ++j) {
+          const double xj = lane_value(xb, j);
+          gt += (xj > xb) ? 1 : 0;
+          ge += (xj >= xb) ? 1 : 0;
+        }
+        // the cutoff is the (M - na)-th largest (0-based) of the boundary bin: the value with gt <= M - na < ge
+        const int want = M - na;
+        const unsigned long long isc = __ballot(lane < nbnd && gt <= want && want < ge);
+        const int src = __ffsll((long long)isc) - 1;
+        const double xcut = lane_value(xb, src);
+        const int n = na + __builtin_amdgcn_readlane(gt, src);  // draws strictly above the cutoff
+        const double e_cut = exp_tab(xcut, tb.tab);
+        double s1_all, s2_all;
+        wave_all2<R_SUM>(s1, s2, s1_all, s2_all);
+        double* wy = F->ws_y + r * (int64_t)F->ws_stride;
+        if (n > 4) {
+          // y = e^x - e^xcut (psis.py:147) in the candidates' order (descending up to the order inside a bin), zeros from n
+          // up to the row stride; the boundary bin's tail members follow the higher bins
+          for (int j = lane; j < F->ws_stride; j += kWave) {
+            const double ej = exp_tab(sm.sa[j < na ? j : 0], tb.tab);
+            if (j < na || j >= n) wy[j] = j < na ? ej - e_cut : 0.0;
+          }
+          const bool mine = lane < nbnd && xb > xcut;
+          const unsigned long long mm = __ballot(mine);
+          const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
+          const double eb = exp_tab(xb, tb.tab);
+          if (mine) wy[na + (int)pos] = eb - e_cut;
+        }
+        if (lane == 0) {
+          double* ws = F->ws_s + r * 8;
+          ws[0] = m; ws[1] = mn; ws[2] = s1_all; ws[3] = s2_all; ws[4] = e_cut; ws[5] = (double)n;
+        }
+      }
+      return;
     }
     if (lane < 4) sm.sa[C1 + lane] = -INF;  // sentinels for the 4-wide reads of the ranking loop
     wave_sync();

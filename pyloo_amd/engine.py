@@ -258,6 +258,42 @@ class Engine:
                                  float(scale_value), PLA_HOST, None, p(lppd_i), p(var_i), p(waic_i), p(agg)))
         return {"lppd_i": lppd_i, "var_i": var_i, "waic_i": waic_i, "agg": agg}
 
+    # ------------------------------------------------------------------ weighted expectations
+    def e_loo(self, x, log_weights, log_ratios=None, tail_len=20):
+        """(n_obs, n_draws) draws ``x`` + log-weights (+ raw log ratios) -> ``dict(mean, var, k_mean, k_var, k_none)``
+        (``pla_e_loo``: e_loo.py:214-236 per observation).  NumPy in -> NumPy out; CUDA tensors in -> CUDA tensors out."""
+        if _is_torch_tensor(x):
+            import torch
+
+            mats = [x, log_weights] + ([log_ratios] if log_ratios is not None else [])
+            if any((not _is_torch_tensor(m)) or m.shape != x.shape or m.dim() != 2 for m in mats):
+                raise ValueError("x, log_weights and log_ratios must be 2-D CUDA tensors of one shape")
+            dt = torch.float64 if any(m.dtype == torch.float64 for m in mats) else torch.float32
+            mats = [m.to(dt) for m in mats]
+            if any(m.stride() != mats[0].stride() for m in mats) or mats[0].stride(1) <= 0:
+                mats = [m.contiguous() for m in mats]
+            t = mats[0]
+            n, s = t.shape
+            out = {k: torch.empty(n, dtype=torch.float64, device=t.device) for k in ("mean", "var", "k_mean", "k_var", "k_none")}
+            code = _capi.PLA_F64 if dt == torch.float64 else _capi.PLA_F32
+            p = lambda m: C.c_void_p(m.data_ptr())  # noqa: E731
+            check(self._lib.pla_e_loo(self._h, p(mats[0]), p(mats[1]), p(mats[2]) if len(mats) > 2 else None, code, n, s,
+                                      t.stride(0), t.stride(1), int(tail_len), PLA_DEVICE, self._stream(),
+                                      *(p(out[k]) for k in ("mean", "var", "k_mean", "k_var", "k_none"))))
+            return out
+        mats = [np.asarray(x), np.asarray(log_weights)] + ([np.asarray(log_ratios)] if log_ratios is not None else [])
+        if any(m.ndim != 2 or m.shape != mats[0].shape for m in mats):
+            raise ValueError("x, log_weights and log_ratios must be 2-D arrays of one shape")
+        dt = np.float32 if all(m.dtype == np.float32 for m in mats) else np.float64
+        mats = [np.ascontiguousarray(m, dtype=dt) for m in mats]
+        n, s = mats[0].shape
+        out = {k: np.empty(n) for k in ("mean", "var", "k_mean", "k_var", "k_none")}
+        p = lambda m: m.ctypes.data_as(C.c_void_p)  # noqa: E731
+        check(self._lib.pla_e_loo(self._h, p(mats[0]), p(mats[1]), p(mats[2]) if len(mats) > 2 else None, dtype_code(dt), n, s,
+                                  s, 1, int(tail_len), PLA_HOST, None,
+                                  *(p(out[k]) for k in ("mean", "var", "k_mean", "k_var", "k_none"))))
+        return out
+
     # ------------------------------------------------------------------ reductions
     def reduce_pointwise(self, diag, loo_i, lppd_i, good_k):
         if _is_torch_tensor(loo_i):

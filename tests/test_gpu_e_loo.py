@@ -1,0 +1,105 @@
+"""``e_loo`` on the device (``-m gpu``): weighted mean / variance / sd and the function-specific Pareto k of ``pla_e_loo``
+against the golden vectors of the reference's own helpers (tests/golden/make_golden_e_loo.py) and against the oracle on
+seeded inputs, through the C ABI and through the ``pyloo_amd.e_loo`` front."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import psis_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["s4000", "s1000", "s257", "s64", "s16", "s4", "edges_s500", "s1000_f32"]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from pyloo_amd.engine import get_engine
+
+    return get_engine(0)
+
+
+def same(got, want, rtol, what):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), f"{what}: NaN pattern {got} vs {want}"
+    inf = np.isinf(want)
+    assert np.array_equal(np.isinf(got), inf) and np.array_equal(got[inf], want[inf]), f"{what}: inf pattern"
+    ok = np.isfinite(want)
+    np.testing.assert_allclose(got[ok], want[ok], rtol=rtol, atol=1e-12, err_msg=what)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_golden_rows(eng, case):
+    g = load_golden("e_loo")
+    x, lw, lr = (g[f"{case}_{k}"] for k in ("x", "lw", "lr"))
+    res = eng.e_loo(x, lw, lr)
+    # f32 input: the parity target is the reference on the f64-upcast data; its own f32 run is ~1e-6 away
+    rtol = 1e-9 if x.dtype == np.float64 else 2e-5
+    same(res["mean"], g[f"{case}_mean"], rtol, "mean")
+    same(res["var"], g[f"{case}_var"], rtol * 10, "variance")
+    for key in ("k_mean", "k_var", "k_none"):
+        same(res[key], g[f"{case}_{key}"], 1e-14, key)
+
+
+@pytest.mark.parametrize("S,N,dt", [(4000, 64, np.float64), (1000, 40, np.float32), (20000, 6, np.float64), (37, 20, np.float64)])
+def test_seeded_vs_oracle(eng, S, N, dt):
+    rng = np.random.default_rng(S + N)
+    lr = (rng.uniform(0.1, 0.9, size=(N, 1)) * rng.exponential(size=(N, S))).astype(dt)
+    x = (rng.normal(size=(N, S)) * 2.0 + 0.3).astype(dt)
+    M = orc.tail_count(S, 1.0)
+    lw, _ = eng.importance_weights(lr, M, "psis") if S > M + 1 and S >= 64 else (lr, None)
+    want = orc.e_loo_arrays(x.astype(np.float64), lw.astype(np.float64), lr.astype(np.float64))
+    res = eng.e_loo(x, lw, lr)
+    same(res["mean"], want["mean"], 1e-9, "mean")
+    same(res["var"], want["var"], 1e-8, "variance")
+    for key in ("k_mean", "k_var", "k_none"):
+        same(res[key], want[key], 1e-14, key)
+    no_ratios = eng.e_loo(x, lw)  # log_ratios defaults to the log-weights (e_loo.py:223-224)
+    want2 = orc.e_loo_arrays(x.astype(np.float64), lw.astype(np.float64), None)
+    same(no_ratios["k_mean"], want2["k_mean"], 1e-14, "k_mean without ratios")
+    same(no_ratios["mean"], want["mean"], 1e-9, "mean without ratios")
+
+
+def test_device_tensors_and_front(eng):
+    import torch
+
+    import pyloo_amd as pl
+
+    rng = np.random.default_rng(3)
+    shape = (5, 7, 2000)  # (*obs, n_draws)
+    lr = 0.5 * rng.exponential(size=shape)
+    x = rng.normal(size=shape) + 1.0
+    lw, _ = pl.psislw(lr, reff=1.0)
+    want = orc.e_loo_arrays(x.reshape(-1, 2000), np.asarray(lw).reshape(-1, 2000), lr.reshape(-1, 2000))
+    for kind, key, kkey in (("mean", "mean", "k_mean"), ("variance", "var", "k_var"), ("sd", "sd", "k_var")):
+        r = pl.e_loo(x, log_weights=lw, log_ratios=lr, type=kind)
+        assert np.asarray(r.value).shape == shape[:-1]
+        same(np.asarray(r.value).ravel(), want[key], 1e-9, kind)
+        same(np.asarray(r.pareto_k).ravel(), want[kkey], 1e-14, "pareto_k")
+        k = np.asarray(r.pareto_k).ravel()
+        np.testing.assert_array_equal(np.asarray(r.min_ss).ravel(), [orc.pareto_min_ss(v) for v in k])
+        np.testing.assert_array_equal(np.asarray(r.convergence_rate).ravel(), [orc.pareto_convergence_rate(v, 2000) for v in k])
+        assert np.all(np.asarray(r.khat_threshold) == orc.pareto_khat_threshold(2000))
+    # weights instead of log-weights (e_loo.py:202-203)
+    r = pl.e_loo(x, weights=np.exp(lw), type="mean")
+    same(np.asarray(r.value).ravel(), want["mean"], 1e-9, "mean from weights")
+    # CUDA tensors in, CUDA tensors out
+    tx, tl, tr = (torch.from_numpy(np.ascontiguousarray(a.reshape(-1, 2000))).cuda() for a in (x, np.asarray(lw), lr))
+    res = eng.e_loo(tx, tl, tr)
+    torch.cuda.synchronize()
+    assert res["mean"].is_cuda
+    same(res["mean"].cpu().numpy(), want["mean"], 1e-9, "mean (device)")
+    same(res["k_var"].cpu().numpy(), want["k_var"], 1e-14, "k_var (device)")
+    # k_hat / compute_pareto_k fronts
+    assert pl.k_hat(x[0, 0], lr[0, 0]) == want["k_mean"][0]
+    assert pl.k_hat(None, lr[0, 0]) == want["k_none"][0]
+    same(np.asarray(pl.compute_pareto_k(x, lr)).ravel(), want["k_mean"], 1e-14, "compute_pareto_k")
+    with pytest.raises(ValueError):
+        pl.e_loo(x, log_weights=lw, type="median")
+    with pytest.raises(ValueError):
+        pl.e_loo(x, type="mean")
+    with pytest.raises(ValueError):
+        pl.e_loo(x, log_weights=lw, type="quantile")
+    with pytest.raises(ValueError):
+        pl.compute_pareto_k(x, lr, tail_len=4)

@@ -134,3 +134,30 @@ def test_vectorised_backend_equals_the_loop():
         assert np.array_equal(np.isnan(a[key]), np.isnan(b[key])), key
         ok = np.isfinite(a[key])
         np.testing.assert_allclose(b[key][ok], a[key][ok], rtol=1e-12, atol=1e-13)
+
+
+# ---------------------------------------------------------------------------------------------
+# e_loo: weighted expectations and their k (fixtures: tests/golden/make_golden_e_loo.py, the reference's own helpers)
+# ---------------------------------------------------------------------------------------------
+E_LOO_CASES = ["s4000", "s1000", "s257", "s64", "s16", "s4", "edges_s500", "s1000_f32"]
+
+
+@pytest.mark.parametrize("case", E_LOO_CASES)
+def test_e_loo_rows(case):
+    g = load_golden("e_loo")
+    x, lw, lr = (g[f"{case}_{k}"] for k in ("x", "lw", "lr"))
+    got = orc.e_loo_arrays(x, lw, lr, probs=g["probs"])
+    for key in ("mean", "var", "quant", "k_mean", "k_var", "k_none"):
+        want = g[f"{case}_{key}"]
+        assert np.array_equal(np.isnan(got[key]), np.isnan(want)), key
+        ok = ~np.isnan(want)
+        np.testing.assert_allclose(got[key][ok], want[ok], rtol=1e-12, atol=0, err_msg=f"{case} {key}")
+
+
+def test_e_loo_scalar_diagnostics():
+    g = load_golden("e_loo")
+    ks = g["diag_k"]
+    np.testing.assert_array_equal(np.array([orc.pareto_min_ss(k) for k in ks]), g["diag_min_ss"])
+    for s in (16, 500, 4000):
+        assert orc.pareto_khat_threshold(s) == float(g[f"diag_threshold_{s}"])
+        np.testing.assert_array_equal(np.array([orc.pareto_convergence_rate(k, s) for k in ks]), g[f"diag_rate_{s}"])
