@@ -49,7 +49,7 @@ struct pla_engine {
   // frozen: the workspace may be referenced by a captured HIP graph; a call that would have to reallocate any of
   // it returns PLA_ERR_FROZEN instead (pla_engine_set_frozen)
   bool frozen = false;
-  unsigned long long* counters = nullptr;  // [4] device
+  unsigned long long* counters = nullptr;  // [16] device: [0] rows on the slow list, [1] running total, [2..3] clock probe, [8..15] reasons (profiling builds)
   double* d_red = nullptr;                 // reduction partials
   // staging for PLA_HOST callers (grown on demand)
   void* d_in = nullptr;
@@ -66,6 +66,8 @@ struct pla_engine {
   std::vector<L1Table> l1_tables;
   void* d_ws = nullptr;    // hand-over buffers of the split LOO pass: [n][stride] tail values + [n][8] scalars
   size_t d_ws_bytes = 0;
+  void* d_col = nullptr;   // observations-fastest LOO (pla_col.h): candidate lists + scalars of one block of observations
+  size_t d_col_bytes = 0;
   void* d_rows = nullptr;  // clamped copy of a caller's device row-index list
   void* d_slab = nullptr;  // host path, observations-fastest input: (n_draws, block of observations) slab before the transpose
   size_t d_slab_bytes = 0;
@@ -229,9 +231,9 @@ int pla_engine_create(int device, pla_engine** out) {
   pla_engine* e = new (std::nothrow) pla_engine();
   if (!e) return fail(PLA_ERR_NOMEM, "out of host memory");
   e->device = device;
-  hipError_t he = hipMalloc((void**)&e->counters, 4 * sizeof(unsigned long long));
+  hipError_t he = hipMalloc((void**)&e->counters, 16 * sizeof(unsigned long long));
   if (he == hipSuccess) he = hipMalloc((void**)&e->d_red, (size_t)pla::reduce_workspace_doubles() * sizeof(double));
-  if (he == hipSuccess) he = hipMemset(e->counters, 0, 4 * sizeof(unsigned long long));
+  if (he == hipSuccess) he = hipMemset(e->counters, 0, 16 * sizeof(unsigned long long));
   for (int i = 0; i < pla_engine::kTimingRing && he == hipSuccess; ++i) {
     he = hipEventCreate(&e->ev0[i]);
     if (he == hipSuccess) he = hipEventCreate(&e->ev1[i]);
@@ -257,6 +259,7 @@ int pla_engine_destroy(pla_engine* e) {
   for (auto& t : e->l1_tables) (void)hipFree(t.d);
   if (e->d_ws) (void)hipFree(e->d_ws);
   if (e->d_rows) (void)hipFree(e->d_rows);
+  if (e->d_col) (void)hipFree(e->d_col);
   if (e->d_slab) (void)hipFree(e->d_slab);
   for (int i = 0; i < pla_engine::kTimingRing; ++i) {
     if (e->ev0[i]) (void)hipEventDestroy(e->ev0[i]);
@@ -428,6 +431,12 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
   hipStream_t s = (hipStream_t)stream;
   const size_t esz = dtype == PLA_F64 ? 8 : 4;
   const bool ingest = obs_fastest_device(mem_space, row_index, n_src, n_draws, stride_obs, stride_draw);
+  // observations-fastest PSIS-LOO: the lane-per-observation kernels read the matrix as it lies (pla_col.h); PLA_INGEST_TRANSPOSE=1
+  // keeps round 1's transposing ingestion (A/B runs), which also serves the shapes the column kernels do not take
+  constexpr int64_t kColBlock = 262144;  // observations per launch: 2 GB of candidate lists
+  int col_kq = 0;
+  static const bool force_transpose = getenv("PLA_INGEST_TRANSPOSE") && atoi(getenv("PLA_INGEST_TRANSPOSE")) != 0;
+  const bool use_col = ingest && method == PLA_PSIS && !force_transpose && pla::col_supported((int)n_draws, (int)tail_count, &col_kq);
 
   pla::RowsParams p{};
   p.n_obs = n_obs;
@@ -437,7 +446,7 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
   p.tail_cap = pow2_at_least(p.tail_count);
   p.scale_value = scale_value;
   p.counters = eng->counters;
-  PLA_HIP(hipMemsetAsync(eng->counters, 0, 4 * sizeof(unsigned long long), s));  // [1]: rows left to the general kernel
+  PLA_HIP(hipMemsetAsync(eng->counters, 0, 16 * sizeof(unsigned long long), s));  // [1]: rows left to the general kernel
   if (n_obs > 0) {
     rc = grow(&eng->d_slow, &eng->d_slow_bytes, (size_t)n_obs * sizeof(unsigned));
     if (rc) return rc;
@@ -447,8 +456,8 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
       if (rc) return rc;
       // hand-over buffers of the split pass (one-chunk wave kernel -> fit kernel, pla_fit.h): sized for the
       // rows one launch processes (all of them on the device path, one staging chunk on the host path)
-      if (tail_count <= 250 && n_draws >= 256 && n_draws <= 4096) {  // (the shapes the one-chunk wave kernel takes)
-        const int64_t chunk_rows = staged_chunk_rows(mem_space, ingest, n_obs, n_draws, esz);
+      if ((tail_count <= 250 && n_draws >= 256 && n_draws <= 4096) || (tail_count <= 448 && n_draws >= 256)) {  // (one-chunk / chunked wave kernels)
+        const int64_t chunk_rows = use_col ? (n_obs < kColBlock ? n_obs : kColBlock) : staged_chunk_rows(mem_space, ingest, n_obs, n_draws, esz);
         const int64_t rows = (mem_space == PLA_DEVICE && !ingest) ? n_obs : chunk_rows;
         const int stride = (int)((tail_count + 63) & ~(int64_t)63);  // 16 lanes x 4 values per quad
         rc = grow(&eng->d_ws, &eng->d_ws_bytes, (size_t)rows * (size_t)(stride + 8) * sizeof(double));
@@ -471,6 +480,28 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
       if (!dd) dd = eng->d_pw;
       if (!dl) dl = eng->d_pw + n_obs;
       if (!dp) dp = eng->d_pw + 2 * n_obs;
+    }
+    if (use_col && p.ws_y) {
+      // observations-fastest input, read in place: one lane per observation (pla_col.h), block by block of observations
+      rc = grow(&eng->d_col, &eng->d_col_bytes, pla::col_workspace_bytes(n_obs < kColBlock ? n_obs : kColBlock));
+      if (rc) return rc;
+      p.stride_obs = 1;
+      p.stride_draw = stride_draw;
+      for (int64_t r0 = 0; r0 < n_obs; r0 += kColBlock) {
+        const int64_t nr = (n_obs - r0 < kColBlock) ? (n_obs - r0) : kColBlock;
+        TimedLaunch t(eng, s);
+        p.in = (const char*)ll + (size_t)r0 * esz;
+        p.n_obs = nr;
+        p.diag = dd ? dd + r0 : nullptr;
+        p.loo_i = dl ? dl + r0 : nullptr;
+        p.lppd_i = dp ? dp + r0 : nullptr;
+        PLA_HIP(pla::launch_col(p, dtype, col_kq, eng->d_col, s));
+      }
+      if (agg) {
+        pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, agg, eng->counters + 1};
+        PLA_HIP(pla::launch_reduce(rp, eng->d_red, s));
+      }
+      return PLA_OK;
     }
     if (ingest) {
       // observations-fastest input: transpose a block of rows into the staging buffer, run the pass on it, next block
@@ -512,6 +543,13 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
       PLA_HIP(pla::launch_rows(p, dtype, false, s, t.mid(), t.mid_flag()));
     }
 #if defined(PLA_WAVE_ABLATE) && PLA_WAVE_ABLATE
+    if (getenv("PLA_PRINT_REASONS")) {  // profiling build only: why rows left the fast path
+      unsigned long long h[16];
+      PLA_HIP(hipStreamSynchronize(s));
+      PLA_HIP(hipMemcpy(h, eng->counters, sizeof(h), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[pla] slow rows by reason: range %llu, threshold search %llu, t1>=0 %llu, pads %llu, too few candidates %llu, "
+                      "too many %llu, other %llu, selection/fit %llu\n", h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
+    }
     if (getenv("PLA_PRINT_CLOCK")) {  // profiling build only: core clock seen by one wave of the fast kernel
       unsigned long long h[4];
       PLA_HIP(hipStreamSynchronize(s));
@@ -618,7 +656,7 @@ int pla_importance_weights(pla_engine* eng, const void* logw, int dtype, int64_t
   p.tail_cap = pow2_at_least(p.tail_count);
   p.scale_value = 1.0;
   p.counters = eng->counters;
-  PLA_HIP(hipMemsetAsync(eng->counters, 0, 4 * sizeof(unsigned long long), s));
+  PLA_HIP(hipMemsetAsync(eng->counters, 0, 16 * sizeof(unsigned long long), s));
   if (n_obs > 0) {  // workspace of the fast path (rows it declines, quantile tables)
     rc = grow(&eng->d_slow, &eng->d_slow_bytes, (size_t)n_obs * sizeof(unsigned));
     if (rc) return rc;
@@ -713,7 +751,7 @@ static int waic_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_src, 
   PLA_HIP(hipSetDevice(eng->device));
   hipStream_t s = (hipStream_t)stream;
   const size_t esz = dtype == PLA_F64 ? 8 : 4;
-  PLA_HIP(hipMemsetAsync(eng->counters, 0, 4 * sizeof(unsigned long long), s));  // [1]: replaced entries
+  PLA_HIP(hipMemsetAsync(eng->counters, 0, 16 * sizeof(unsigned long long), s));  // [1]: replaced entries
 
   if (mem_space == PLA_DEVICE) {
     double *dl = lppd_i, *dv = var_i, *dw = waic_i;

@@ -24,14 +24,17 @@ namespace pla {
 
 constexpr int kChunkDraws = kWave * kWaveSlots;  // 4096
 
-template <typename T, int VEC, typename SM, typename TB>
+template <typename T, int VEC, typename SM, typename TB, bool SPLIT = false>
 __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const FastParams& F, SM& sm, const TB& tb,
                                                     const int64_t r, T (&v)[kWaveSlots], const T* row, const T* rp_next) {
   constexpr int EPT = kWaveSlots;
   constexpr int NQ = EPT / VEC;
   constexpr int kCand = SM::Caps::kCand;
   constexpr bool LW = false;
-  const int lane = wave_lane();
+  // (opaque to the optimiser: otherwise every lane-derived mask of the later phases is hoisted out of the ROW loop into
+  // scalar registers, which that loop does not have -- they were being spilled to vector lanes)
+  int lane = wave_lane();
+  asm volatile("" : "+v"(lane));
   const int S = __builtin_amdgcn_readfirstlane(P.n_draws);
   const int M = __builtin_amdgcn_readfirstlane(P.tail_count);
   const int gsz = __builtin_amdgcn_readfirstlane(F.gsz);
@@ -82,6 +85,8 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
     m_run = fmax(m_run, mc);
     mn_run = fmin(mn_run, mnc);
     if (ch == 0) {
+      // (a row that is its own last chunk has pads: make them the row minimum before anything is counted)
+      if (last) pad_tail<T, VEC, NQ - 1, true>(v, qfull, qrem, (T)(-mn_run));
       // speculative threshold from the first chunk's group maxima (see pla_wave.h); shift = its maximum
       mp = mc;
       double lo = wave_all<R_MIN>(gs), hi = mc;
@@ -90,6 +95,10 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
         const double mid = 0.5 * (lo + hi);
         const int below = __popcll(__ballot(gs < mid));
         if (below >= kq) hi = mid; else lo = mid;
+      }
+      if (mc - mnc < kWaveMaxRange) {
+        // (the exact counts look at this first chunk only: the rest of the row has not been read yet)
+        if (!wave_threshold_check<T, VEC, false>(v, F, mnc, mc, hi)) slow = true;
       }
       t1p = hi - mp;
       if (!(t1p < 0.0)) slow = true;
@@ -189,22 +198,32 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
     const int sh = (span >> 9) ? (32 - __builtin_clz((unsigned)(span >> 9))) : 0;
     const int nvl = (S - (nch - 1) * kChunkDraws) / VEC;  // qfull / qrem of the last chunk (unused by LOO mode)
     wave_sync();
-    wave_back<T, VEC, LW, SM, TB>(P, sm, tb, r, v, lane, S, M, mestM, logS, dbgs, m, mn, R, delta, s1, s2, ncand, k1, sh,
-                                  magic, c256, nvl / kWave, nvl % kWave, slow, khat, loo, lppd);
+    if constexpr (SPLIT) {
+      // split pass: selection here, fit / smoothing / outputs in fit_rows_kernel (16 lanes per observation, pla_fit.h).
+      // The second sum is brought to the true shift as well: e^-x = e^-x' e^(m - m')  (R < 690 keeps it finite)
+      s2 *= exp_tab(delta, tb.tab);
+      wave_select_split<SM, TB, (SM::Caps::kMaxTail + 63) / 64>(F, sm, tb, r, lane, M, m, mn, s1, s2, ncand, k1, sh, magic, c256, slow);
+    } else {
+      wave_back<T, VEC, LW, SM, TB>(P, sm, tb, r, v, lane, S, M, mestM, logS, dbgs, m, mn, R, delta, s1, s2, ncand, k1, sh,
+                                    magic, c256, nvl / kWave, nvl % kWave, slow, khat, loo, lppd);
+    }
   }
   if (lane == 0) {
     if (slow) {
       const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
       F.slow_list[idx] = (unsigned)r;
-    } else {
-      if (P.diag) P.diag[r] = khat;
-      if (P.loo_i) P.loo_i[r] = P.scale_value * loo;
-      if (P.lppd_i) P.lppd_i[r] = lppd;
+      if constexpr (SPLIT) F.ws_s[r * 8 + 5] = -1.0;  // tail length -1: on the list, nothing for the fit kernel
+    } else if constexpr (!SPLIT) {
+      double *pd = P.diag, *pl = P.loo_i, *pp = P.lppd_i;
+      asm volatile("" : "+s"(pd), "+s"(pl), "+s"(pp));  // (null tests inside the row loop, not hoisted into scalar registers it lacks)
+      if (pd) pd[r] = khat;
+      if (pl) pl[r] = P.scale_value * loo;
+      if (pp) pp[r] = lppd;
     }
   }
 }
 
-template <typename T, int VEC, class CAP>
+template <typename T, int VEC, class CAP, bool SPLIT = false>
 __global__ __launch_bounds__(kWave * CAP::kWaves, 1) void wave_loo_chunked_kernel(RowsParams P, FastParams F) {
   using SM = WaveSmemT<CAP>;
   using TB = WaveTablesT<CAP>;
@@ -228,7 +247,7 @@ __global__ __launch_bounds__(kWave * CAP::kWaves, 1) void wave_loo_chunked_kerne
   for (int64_t r = w0; r < P.n_obs; r += nw) {
     const int64_t rn = r + nw;
     const T* nxt = rn < P.n_obs ? base + PLA_ROW_OFFSET(P, rn) : nullptr;
-    wave_loo_row_chunked<T, VEC, SM, TB>(P, F, sm, tb, r, v, cur, nxt);
+    wave_loo_row_chunked<T, VEC, SM, TB, SPLIT>(P, F, sm, tb, r, v, cur, nxt);
     cur = nxt;
   }
 }

@@ -46,6 +46,9 @@ struct FastParams {
   int mest_M;                     // 30 + isqrt(M)
   // split pass (pla_fit.h): hand-over buffers of the wave kernel, null when the pass is fused
   int sample_bits = 0;            // B of bitrev_order: which slots the first `gsz` visited ones are
+  // check of the speculative threshold before the sweep (wave_threshold_check): it is kept when cr_lo <= #(draws of the
+  // register block at or above it) <= cr_hi, otherwise replaced by one found by bisection on such counts.  cr_hi == 0: no check.
+  int cr_lo = 0, cr_hi = 0;
   double* ws_y = nullptr;         // [n_obs][ws_stride] ascending tail values
   double* ws_s = nullptr;         // [n_obs][8] scalars
   int ws_stride = 0;

@@ -29,8 +29,9 @@
 
 namespace pla {
 
-constexpr int kFitWaves = 4;       // waves per workgroup (they share the tables)
+constexpr int kFitWaves = 4;       // waves per workgroup (they share the tables); 2 for the long-tail instantiations (LDS)
 constexpr int kFitGrid = 48;       // three grid points per lane: m_est = 30 + isqrt(n) <= 46 for n <= 256
+constexpr int kFitGridBig = 64;    // four per lane: tails up to 448 values (m_est <= 51), S = 20 000 at reff = 1
 constexpr int kFitCoefStride = 6;  // (VALU grid pass) doubles per quad in LDS, five used: 48 bytes keep the 16-byte alignment
 #ifndef PLA_FIT_MFMA
 #define PLA_FIT_MFMA 1  // 1: the quartics of the grid pass on the matrix cores (v_mfma_f64_16x16x4_f64); 0: Horner on the VALU
@@ -76,8 +77,10 @@ __device__ __forceinline__ int row_all_add(int v) {
   return v;
 }
 
-template <int NQ>
-__global__ __launch_bounds__(kWave * kFitWaves, 2) void fit_rows_kernel(FitParams Q) {
+// NQ: 64-value blocks of the tail (4 NQ values per lane); G: grid points per lane (16 G >= m_est); W: waves per workgroup
+template <int NQ, int G = 3, int W = kFitWaves>
+__global__ __launch_bounds__(kWave * W, 2) void fit_rows_kernel(FitParams Q) {
+  constexpr int kFitWaves = W;  // (shadows the default: everything below is per instantiation)
   __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];
   __shared__ __attribute__((aligned(16))) double lt[2 * kLogTabN];
   __shared__ __attribute__((aligned(16))) double l1s[64 * NQ];
@@ -119,9 +122,9 @@ __global__ __launch_bounds__(kWave * kFitWaves, 2) void fit_rows_kernel(FitParam
   // B[k][col] = g_col^(k+1).  Operand lane (t, rho) supplies A[row t][k rho] and B[k rho][col t].
   const double* ckA = ck + ((rho + 1) * 4 + (t & 3)) * QN + (t >> 2);
   const double* ckC = ck + rho * QN;
-  double gp[3];
+  double gp[G];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
+  for (int c = 0; c < G; ++c) {
     const int j = t + 16 * c;
     const double gj = Q.b_grid[j < mestM ? j : 0], g2 = gj * gj;
     gp[c] = rho == 0 ? gj : (rho == 1 ? g2 : (rho == 2 ? g2 * gj : g2 * g2));
@@ -131,11 +134,11 @@ __global__ __launch_bounds__(kWave * kFitWaves, 2) void fit_rows_kernel(FitParam
   double* ys_base = coef + (size_t)(wv * 4 * 16 * NQ) * kFitCoefStride;
 #endif
   (void)ys_base;
-  // grid coordinates of this lane: j = t, t + 16, t + 32
-  double g[3];
-  bool gact[3];
+  // grid coordinates of this lane: j = t, t + 16, t + 32 (, t + 48)
+  double g[G];
+  bool gact[G];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
+  for (int c = 0; c < G; ++c) {
     const int j = t + 16 * c;
     gact[c] = j < mestM;
     g[c] = Q.b_grid[gact[c] ? j : 0];
@@ -247,8 +250,13 @@ __global__ __launch_bounds__(kWave * kFitWaves, 2) void fit_rows_kernel(FitParam
     }
     wave_sync();
     // ---- grid pass: three running products per lane over the 16 NQ quads of the observation -------------------
-    double pm[3] = {1.0, 1.0, 1.0};
-    int pe[3] = {0, 0, 0};
+    double pm[G];
+    int pe[G];
+#pragma unroll
+    for (int c = 0; c < G; ++c) {
+      pm[c] = 1.0;
+      pe[c] = 0;
+    }
 #if PLA_FIT_MFMA
 #pragma unroll 1
     for (int q4 = 0; q4 < QN; q4 += 8) {
@@ -258,14 +266,14 @@ __global__ __launch_bounds__(kWave * kFitWaves, 2) void fit_rows_kernel(FitParam
         const double2 c01 = *reinterpret_cast<const double2*>(ckC + q4 + u), c23 = *reinterpret_cast<const double2*>(ckC + q4 + u + 2);
         const v4d cin = {c01.x, c01.y, c23.x, c23.y};
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < G; ++c) {
           const v4d d = __builtin_amdgcn_mfma_f64_16x16x4f64(a, gp[c], cin, 0, 0, 0);
           pm[c] *= (d[0] * d[1]) * (d[2] * d[3]);
         }
       }
       // factors within 2^+-120 per quad: eight fit between renormalisations
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
+      for (int c = 0; c < G; ++c) {
         pe[c] += __builtin_amdgcn_frexp_exp(pm[c]);
         pm[c] = __builtin_amdgcn_frexp_mant(pm[c]);
       }
@@ -279,11 +287,11 @@ __global__ __launch_bounds__(kWave * kFitWaves, 2) void fit_rows_kernel(FitParam
         const double2 c01 = *reinterpret_cast<const double2*>(cq), c23 = *reinterpret_cast<const double2*>(cq + 2);
         const double c4 = cq[4];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) pm[c] *= fma(g[c], fma(g[c], fma(g[c], fma(g[c], c4, c23.y), c23.x), c01.y), c01.x);
+        for (int c = 0; c < G; ++c) pm[c] *= fma(g[c], fma(g[c], fma(g[c], fma(g[c], c4, c23.y), c23.x), c01.y), c01.x);
       }
       // factors within 2^+-120 per quad: eight fit between renormalisations
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
+      for (int c = 0; c < G; ++c) {
         pe[c] += __builtin_amdgcn_frexp_exp(pm[c]);
         pm[c] = __builtin_amdgcn_frexp_mant(pm[c]);
       }
@@ -291,15 +299,18 @@ __global__ __launch_bounds__(kWave * kFitWaves, 2) void fit_rows_kernel(FitParam
 #endif
     wave_sync();  // (the next group's coefficients are written after these reads)
     // ---- profile likelihood, softmax weights, posterior mean of b (psis.py:190-201) --------------------------
-    double ls[3], bb[3], lp[3];
-    bool tiny[3];
+    double ls[G], bb[G], lp[G];
+    bool tiny[G];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < G; ++c) {
       bb[c] = fma(g[c], cb, db);
       tiny[c] = gact[c] && fabs(bb[c] * yn) < 0x1p-14;  // 1 - b y rounds away the digits of b y
       lp[c] = log_tab(pm[c], lt) + (double)pe[c] * kLn2;
     }
-    if (__ballot(tiny[0] || tiny[1] || tiny[2]) != 0ull) {
+    bool any_tiny = false;
+#pragma unroll
+    for (int c = 0; c < G; ++c) any_tiny = any_tiny || tiny[c];
+    if (__ballot(any_tiny) != 0ull) {
       // (one observation in ~2000) sum_i log1p(-b y_i) = -(b p1 + b^2 p2/2 + b^3 p3/3 + b^4 p4/4) + O((b y)^5) from the
       // power sums p_k of the tail: to 2^-56 relative for |b y| < 2^-14
       double p1 = 0.0, p2 = 0.0, p3 = 0.0, p4 = 0.0;
@@ -319,29 +330,35 @@ __global__ __launch_bounds__(kWave * kFitWaves, 2) void fit_rows_kernel(FitParam
       p3 = row_all(p3, op_sum);
       p4 = row_all(p4, op_sum);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
+      for (int c = 0; c < G; ++c) {
         const double b = bb[c];
         if (tiny[c]) lp[c] = -b * fma(b, fma(b, fma(b, 0.25 * p4, p3 * (1.0 / 3.0)), 0.5 * p2), p1);
       }
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < G; ++c) {
       const double b = bb[c];
       const double kj = lp[c] * rn;                                                               // psis.py:190
       const double l = nn * (log_tab(gact[c] ? -div_fast(b, kj) : 1.0, lt) - kj - 1.0);           // psis.py:191
       if (gact[c] && l != l) bad = true;  // NaN anywhere: every weight is NaN in the reference; the general kernel does that
       ls[c] = gact[c] ? l : -INF;
     }
-    const double lmax = row_all(vmax_nc<false>(vmax_nc<false>(ls[0], ls[1]), ls[2]), op_max);
-    if (!(fabs(lmax) < INF)) bad = true;
-    double w[3];
+    double lmx = ls[0];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) w[c] = gact[c] ? exp_neg(ls[c] - lmax, tab) : 0.0;                // psis.py:192
-    const double se = row_all((w[0] + w[1]) + w[2], op_sum);
+    for (int c = 1; c < G; ++c) lmx = vmax_nc<false>(lmx, ls[c]);
+    const double lmax = row_all(lmx, op_max);
+    if (!(fabs(lmax) < INF)) bad = true;
+    double w[G];
+#pragma unroll
+    for (int c = 0; c < G; ++c) w[c] = gact[c] ? exp_neg(ls[c] - lmax, tab) : 0.0;                // psis.py:192
+    double wsum = w[0];
+#pragma unroll
+    for (int c = 1; c < G; ++c) wsum += w[c];
+    const double se = row_all(wsum, op_sum);
     // the weights stay unnormalised (b_post is a ratio): w/se >= 10 eps  <=>  w >= 10 eps se   (psis.py:194-197)
     double swl = 0.0, bwl = 0.0;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < G; ++c) {
       const bool keep = w[c] >= (10.0 * kEps) * se;
       swl += keep ? w[c] : 0.0;
       bwl += keep ? bb[c] * w[c] : 0.0;

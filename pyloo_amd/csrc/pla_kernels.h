@@ -70,6 +70,12 @@ hipError_t launch_waic(const void* in, const int64_t* row_index, int dtype, int6
 hipError_t launch_e_loo(const void* x, const void* lw, const void* lr, int dtype, int64_t n_obs, int n_draws, int64_t stride_obs,
                         int64_t stride_draw, int tail_len, double* mean, double* var, double* k_mean, double* k_var, double* k_none,
                         hipStream_t stream);
+// Observations-fastest PSIS-LOO without a transposing pass (pla_col.h): lane-per-observation sweep + per-observation
+// selection + the fit kernel of the split pass.  `p`: in = first observation of the block, stride_obs = 1, stride_draw = ld,
+// ws_y / ws_s / slow_list / counters / l1_table set as for the split pass.  col_ws: col_workspace_bytes(n_obs) of device memory.
+bool col_supported(int n_draws, int tail_count, int* kq);
+size_t col_workspace_bytes(int64_t n_obs);
+hipError_t launch_col(const RowsParams& p, int dtype, int kq, void* col_ws, hipStream_t stream);
 // largest tail count the kernels accept
 int max_tail_count();
 

@@ -23,6 +23,7 @@
 #include "pla_is.h"
 #include "pla_fit.h"
 #include "pla_eloo.h"
+#include "pla_col.h"
 
 namespace pla {
 
@@ -197,7 +198,12 @@ static hipError_t launch_one(const RowsParams& p, hipStream_t stream) {
 // F^gsz = kq/64.  Pick (gsz, kq) so that ~2.2(M+1) draws lie above, with kq large enough for the order
 // statistic to be stable.  Returns false when no setting fits (the general kernel takes the call).
 // `cand_cap`: capacity of the LDS candidate list; only the first min(S, 4096) draws feed the maxima.
-static bool wave_threshold_params(int S, int vec, int M, int* gsz_out, int* kq_out, int* bits_out, int cand_cap = kCandCap) {
+static int debug_flag(const char* name);
+struct ThresholdCheck {  // FastParams::cr_lo, cr_hi
+  int cr_lo, cr_hi;
+};
+static bool wave_threshold_params(int S, int vec, int M, int* gsz_out, int* kq_out, int* bits_out, ThresholdCheck* chk,
+                                  int cand_cap = kCandCap) {
 #ifndef PLA_CAND_MULT
 #define PLA_CAND_MULT 2.2
 #endif
@@ -223,6 +229,12 @@ static bool wave_threshold_params(int S, int vec, int M, int* gsz_out, int* kq_o
   *gsz_out = best_g;
   *kq_out = best_k;
   *bits_out = bits;
+  // acceptance band of the threshold check, in draws of the register block (S0 of the row's S; pads never count): the whole
+  // row must end with M + 1 .. cand_cap draws above the threshold; 25 % / 15 % of margin for what the first chunk of a long
+  // row cannot know
+  static const int off = debug_flag("PLA_NO_THRESHOLD_CHECK");
+  chk->cr_lo = (int)std::ceil(1.25 * (M + 1) / S * S0);
+  chk->cr_hi = off ? 0 : (int)std::floor(0.85 * cand_cap / S * S0);
   return true;
 }
 
@@ -242,8 +254,35 @@ static int64_t wave_grid(int64_t n_obs, int waves) {
   return grid;
 }
 
+// second kernel of a split LOO pass: fit / smoothing / outputs for the tails the selection kernel handed over (pla_fit.h)
+static hipError_t launch_fit(const RowsParams& p, const FastParams& f, int mestM, hipStream_t stream) {
+  FitParams q{p.ws_y, p.ws_s, p.ws_stride, p.n_obs, p.n_draws, p.tail_count, mestM, f.log_S, p.scale_value, p.l1_table,
+              p.l1_table + p.tail_count, p.diag, p.loo_i, p.lppd_i, p.slow_list, p.counters};
+  const int nq = p.ws_stride / 64;
+  const int waves = nq <= 4 ? kFitWaves : 2;
+  int64_t g3 = ((p.n_obs + 3) / 4 + waves - 1) / waves;  // four observations per wave
+  if (g3 > 256 * 8) g3 = 256 * 8;
+  const dim3 fg((unsigned)g3), fb(kWave * waves);
+  switch (nq) {
+    case 1: hipLaunchKernelGGL(fit_rows_kernel<1>, fg, fb, 0, stream, q); break;
+    case 2: hipLaunchKernelGGL(fit_rows_kernel<2>, fg, fb, 0, stream, q); break;
+    case 3: hipLaunchKernelGGL(fit_rows_kernel<3>, fg, fb, 0, stream, q); break;
+    case 4: hipLaunchKernelGGL(fit_rows_kernel<4>, fg, fb, 0, stream, q); break;
+    case 5: hipLaunchKernelGGL((fit_rows_kernel<5, 4, 2>), fg, fb, 0, stream, q); break;
+    case 6: hipLaunchKernelGGL((fit_rows_kernel<6, 4, 2>), fg, fb, 0, stream, q); break;
+    default: hipLaunchKernelGGL((fit_rows_kernel<7, 4, 2>), fg, fb, 0, stream, q); break;
+  }
+  return hipGetLastError();
+}
+// shapes the split pass covers: hand-over buffers present, tail within the stride, grid within the fit kernel's lanes
+static bool split_ok(const RowsParams& p, int mestM) {
+  if (!p.ws_y || !p.ws_s || p.ws_stride % 64 != 0 || p.tail_count > p.ws_stride) return false;
+  return p.ws_stride <= 256 ? mestM <= kFitGrid : (p.ws_stride <= 448 && mestM <= kFitGridBig);
+}
+
 template <typename T, int VEC, bool LW>
-static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, hipStream_t stream, hipEvent_t after_first, bool* recorded) {
+static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, const ThresholdCheck& chk, hipStream_t stream,
+                              hipEvent_t after_first, bool* recorded) {
   hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   static const int dbg = debug_flag("PLA_DEBUG_SKIP");
@@ -254,11 +293,11 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, hi
   const int mestM = 30 + root_;
   FastParams f{gsz, kq, p.slow_list, p.counters, dbg, p.l1_table, std::log((double)p.n_draws), p.l1_table + p.tail_count, mestM};
   f.sample_bits = bits;
+  f.cr_lo = chk.cr_lo; f.cr_hi = chk.cr_hi;
   // 4 independent waves per workgroup (they share the read-only tables); 8 x 2048 waves keep all
   // 256 CUs (8 waves each) busy with a short tail
   const int64_t grid = wave_grid(p.n_obs, kWavesPerBlock);
-  const bool split = !LW && !fused && !dbg && p.ws_y && p.ws_s && mestM <= kFitGrid && p.ws_stride % 64 == 0 && p.ws_stride <= 256 &&
-                     p.tail_count <= p.ws_stride;
+  const bool split = !LW && !fused && !(dbg & 31) && p.ws_stride <= 256 && split_ok(p, mestM);  // (ablation bits >= 32 live inside the split pass)
   if constexpr (!LW) {
     if (split) {
       // split pass: wave kernel up to the exact selection, then sixteen lanes per observation for the GPD fit,
@@ -271,18 +310,7 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, hi
       e = hipGetLastError();
       if (e != hipSuccess) return e;
       if (after_first && hipEventRecord(after_first, stream) == hipSuccess && recorded) *recorded = true;
-      FitParams q{p.ws_y, p.ws_s, p.ws_stride, p.n_obs, p.n_draws, p.tail_count, mestM, f.log_S, p.scale_value, p.l1_table,
-                  p.l1_table + p.tail_count, p.diag, p.loo_i, p.lppd_i, p.slow_list, p.counters};
-      int64_t g3 = ((p.n_obs + 3) / 4 + kFitWaves - 1) / kFitWaves;  // four observations per wave
-      if (g3 > 256 * 8) g3 = 256 * 8;
-      const dim3 fg((unsigned)g3), fb(kWave * kFitWaves);
-      switch (p.ws_stride / 64) {
-        case 1: hipLaunchKernelGGL(fit_rows_kernel<1>, fg, fb, 0, stream, q); break;
-        case 2: hipLaunchKernelGGL(fit_rows_kernel<2>, fg, fb, 0, stream, q); break;
-        case 3: hipLaunchKernelGGL(fit_rows_kernel<3>, fg, fb, 0, stream, q); break;
-        default: hipLaunchKernelGGL(fit_rows_kernel<4>, fg, fb, 0, stream, q); break;
-      }
-      e = hipGetLastError();
+      e = launch_fit(p, f, mestM, stream);
       if (e != hipSuccess) return e;
     }
   }
@@ -301,20 +329,40 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, hi
 
 // long rows (chunks of 4096 draws) and / or tail counts up to 512: pla_chunked.h
 template <typename T, int VEC, class CAP>
-static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, int bits, hipStream_t stream) {
+static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, int bits, const ThresholdCheck& chk, hipStream_t stream,
+                                 hipEvent_t after_first, bool* recorded) {
   hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
+  static const int fused = debug_flag("PLA_FUSED");
   int root_ = (int)std::sqrt((double)p.tail_count);
   while (root_ * root_ > p.tail_count) --root_;
   while ((root_ + 1) * (root_ + 1) <= p.tail_count) ++root_;
-  FastParams f{gsz, kq, p.slow_list, p.counters, 0, p.l1_table, std::log((double)p.n_draws), p.l1_table + p.tail_count, 30 + root_};
+  const int mestM = 30 + root_;
+  FastParams f{gsz, kq, p.slow_list, p.counters, 0, p.l1_table, std::log((double)p.n_draws), p.l1_table + p.tail_count, mestM};
   f.sample_bits = bits;
+  f.cr_lo = chk.cr_lo; f.cr_hi = chk.cr_hi;
   constexpr int W = CAP::kWaves;  // waves per workgroup; two workgroups per CU (LDS)
   int64_t grid = (p.n_obs + W - 1) / W;
   if (grid > 2048 * 8 / W) grid = 2048 * 8 / W;
-  hipLaunchKernelGGL((wave_loo_chunked_kernel<T, VEC, CAP>), dim3((unsigned)grid), dim3(kWave * W), 0, stream, p, f);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
+  bool split = false;
+  if constexpr (CAP::kMaxTail <= 448) split = !fused && split_ok(p, mestM) && p.ws_stride <= 64 * ((CAP::kMaxTail + 63) / 64);
+  if (split) {
+    if constexpr (CAP::kMaxTail <= 448) {
+      f.ws_y = p.ws_y;
+      f.ws_s = p.ws_s;
+      f.ws_stride = p.ws_stride;
+      hipLaunchKernelGGL((wave_loo_chunked_kernel<T, VEC, CAP, true>), dim3((unsigned)grid), dim3(kWave * W), 0, stream, p, f);
+      e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      if (after_first && hipEventRecord(after_first, stream) == hipSuccess && recorded) *recorded = true;
+      e = launch_fit(p, f, mestM, stream);
+      if (e != hipSuccess) return e;
+    }
+  } else {
+    hipLaunchKernelGGL((wave_loo_chunked_kernel<T, VEC, CAP>), dim3((unsigned)grid), dim3(kWave * W), 0, stream, p, f);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
   constexpr int BLOCK = 256;
   int64_t g2 = p.n_obs < 1024 ? p.n_obs : 1024;
   hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK, false>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap),
@@ -356,8 +404,9 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream, hipEvent
         p.n_draws <= kWave * kWaveSlots && p.n_draws >= 256 && p.tail_count <= kWaveMaxTail &&
         smem_bytes(BLOCK, p.tail_cap) <= 64 * 1024 && p.n_obs <= 0xffffffffll) {
       int gsz = 0, kq = 0, bits = 0;
-      if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits)) {
-        return launch_wave<T, WVEC, LW>(p, gsz, kq, bits, stream, after_first, recorded);
+      ThresholdCheck chk{};
+      if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk)) {
+        return launch_wave<T, WVEC, LW>(p, gsz, kq, bits, chk, stream, after_first, recorded);
       }
     }
     if constexpr (!LW) {
@@ -370,12 +419,13 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream, hipEvent
           p.n_draws >= 256 && p.n_draws <= (1 << 20) && last_chunk >= kWave * WVEC && p.tail_count <= CapsBig::kMaxTail &&
           smem_bytes(BLOCK, p.tail_cap) <= 64 * 1024 && p.n_obs <= 0xffffffffll) {
         int gsz = 0, kq = 0, bits = 0;
-        if (p.tail_count <= CapsMid4::kMaxTail && wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, CapsMid4::kCand))
-          return launch_chunked<T, WVEC, CapsMid4>(p, gsz, kq, bits, stream);
-        if (p.tail_count <= CapsMid::kMaxTail && wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, CapsMid::kCand))
-          return launch_chunked<T, WVEC, CapsMid>(p, gsz, kq, bits, stream);
-        if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, CapsBig::kCand))
-          return launch_chunked<T, WVEC, CapsBig>(p, gsz, kq, bits, stream);
+        ThresholdCheck chk{};
+        if (p.tail_count <= CapsMid4::kMaxTail && wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk, CapsMid4::kCand))
+          return launch_chunked<T, WVEC, CapsMid4>(p, gsz, kq, bits, chk, stream, after_first, recorded);
+        if (p.tail_count <= CapsMid::kMaxTail && wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk, CapsMid::kCand))
+          return launch_chunked<T, WVEC, CapsMid>(p, gsz, kq, bits, chk, stream, after_first, recorded);
+        if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk, CapsBig::kCand))
+          return launch_chunked<T, WVEC, CapsBig>(p, gsz, kq, bits, chk, stream, after_first, recorded);
       }
     }
     if (path == 1) return launch_one<T, BLOCK, 0, LW>(p, stream);
@@ -476,6 +526,54 @@ hipError_t launch_waic(const void* in, const int64_t* row_index, int dtype, int6
   if (n_obs <= 0) return hipSuccess;
   WaicParams p{in, n_obs, n_draws, stride_obs, stride_draw, scale_value, lppd_i, var_i, waic_i, replaced, row_index};
   return dtype == PLA_F64 ? launch_waic_typed<double>(p, stream) : launch_waic_typed<float>(p, stream);
+}
+
+bool col_supported(int n_draws, int tail_count, int* kq) {
+  // threshold: the kq-th smallest of 64 maxima over groups of 8 sampled draws has a fraction F of the row below it,
+  // F^8 = kq / 64; aim at 2.2 (M + 1) draws above it, as in the wave kernel
+  if (n_draws < kColSample || tail_count > CapsSmall::kMaxTail) return false;
+  const double F = 1.0 - 2.2 * (tail_count + 1) / n_draws;
+  if (!(F > 0.5)) return false;
+  const int k = (int)std::lround(64.0 * std::pow(F, 8));
+  if (k < 4 || k > 56) return false;
+  *kq = k;
+  return true;
+}
+size_t col_workspace_bytes(int64_t n_obs) { return (size_t)n_obs * (kColCap + 8) * sizeof(double); }
+
+hipError_t launch_col(const RowsParams& p, int dtype, int kq, void* col_ws, hipStream_t stream) {
+  if (p.n_obs <= 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return e;
+  int root_ = (int)std::sqrt((double)p.tail_count);
+  while (root_ * root_ > p.tail_count) --root_;
+  while ((root_ + 1) * (root_ + 1) <= p.tail_count) ++root_;
+  const int mestM = 30 + root_;
+  ColParams c{p.in, p.n_obs, p.n_draws, p.stride_draw, kq, (double*)col_ws, (double*)col_ws + (size_t)p.n_obs * kColCap};
+  const unsigned g1 = (unsigned)((p.n_obs + 255) / 256);
+  if (dtype == PLA_F64) hipLaunchKernelGGL(col_sweep_kernel<double>, dim3(g1), dim3(256), 0, stream, c);
+  else hipLaunchKernelGGL(col_sweep_kernel<float>, dim3(g1), dim3(256), 0, stream, c);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  FastParams f{0, 0, p.slow_list, p.counters, 0, p.l1_table, std::log((double)p.n_draws), p.l1_table + p.tail_count, mestM};
+  f.ws_y = p.ws_y;
+  f.ws_s = p.ws_s;
+  f.ws_stride = p.ws_stride;
+  int64_t g2 = (p.n_obs + 3) / 4;
+  if (g2 > 256 * 16) g2 = 256 * 16;
+  hipLaunchKernelGGL(col_select_kernel<CapsSmall>, dim3((unsigned)g2), dim3(kWave * 4), 0, stream, c, f, p.tail_count);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = launch_fit(p, f, mestM, stream);
+  if (e != hipSuccess) return e;
+  // rows the column path declined: the general kernel walks them with the matrix's strides
+  constexpr int BLOCK = 256;
+  int64_t g3 = p.n_obs < 1024 ? p.n_obs : 1024;
+  if (dtype == PLA_F64)
+    hipLaunchKernelGGL((slow_rows_kernel<double, BLOCK, false>), dim3((unsigned)g3), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap), stream, p);
+  else
+    hipLaunchKernelGGL((slow_rows_kernel<float, BLOCK, false>), dim3((unsigned)g3), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap), stream, p);
+  return hipGetLastError();
 }
 
 hipError_t launch_e_loo(const void* x, const void* lw, const void* lr, int dtype, int64_t n_obs, int n_draws, int64_t stride_obs,

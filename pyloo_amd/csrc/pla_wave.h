@@ -396,7 +396,78 @@ __device__ __forceinline__ void row_stats(const T (&v)[kWaveSlots], const int gs
   // every row load has landed by now (each order ends on the last vector).  Said explicitly, because the compiler's
   // wait-count bookkeeping loses track across the merge of the four variants and would otherwise guard every later
   // read of the row with a (satisfied, but issued) s_waitcnt vmcnt.
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+#ifndef PLA_STATS_VMCNT
+#define PLA_STATS_VMCNT 0x0F70  // vmcnt(0), expcnt / lgkmcnt untouched
+#endif
+#if PLA_STATS_VMCNT
+  __builtin_amdgcn_s_waitcnt(PLA_STATS_VMCNT);
+#endif
+}
+
+// Number of draws of the register block at or above a raw threshold (pads hold the row minimum by then and never count).  `thr` is in the sign convention of the stored values
+// (LOO mode keeps ll = -raw).  Wave-uniform result.
+__device__ __forceinline__ int wave_sum_int(int v) {  // wave-uniform sum of a per-lane integer
+  v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  v += __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, false);  // row_mirror: every lane has its row's sum
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+         __builtin_amdgcn_readlane(v, 48);
+}
+// cnt += (GE ? a >= b : a <= b), per lane: a compare into vcc and an add-with-carry -- written out because the compiler would
+// first collect the 64 masks of an unrolled count in scalar registers and spill them
+template <bool GE>
+__device__ __forceinline__ void count_if(int& cnt, double a, double b) {
+  if constexpr (GE) asm volatile("v_cmp_ge_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(cnt) : "v"(a), "v"(b) : "vcc");
+  else asm volatile("v_cmp_le_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(cnt) : "v"(a), "v"(b) : "vcc");
+}
+template <bool GE>
+__device__ __forceinline__ void count_if(int& cnt, float a, float b) {
+  if constexpr (GE) asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(cnt) : "v"(a), "v"(b) : "vcc");
+  else asm volatile("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(cnt) : "v"(a), "v"(b) : "vcc");
+}
+template <typename T, bool LW>
+__device__ __forceinline__ int count_above(const T (&v)[kWaveSlots], T thr) {
+  int cnt = 0;  // per lane
+  asm volatile("" : "+v"(thr));
+#pragma unroll
+  for (int i = 0; i < kWaveSlots; ++i) count_if<LW>(cnt, v[i], thr);
+  return wave_sum_int(cnt);
+}
+
+// The speculative threshold comes from an order statistic of per-lane GROUP maxima over a sample of the row: a biased
+// quantile estimate when the draws of a group are dependent (autocorrelated MCMC output: the sample is made of 128-draw
+// blocks) and meaningless for rows that trend or are sorted.  So it is checked against what it is meant to deliver -- the
+// EXACT number of draws of the register block at or above it (two VALU operations per slot) -- and when that count is
+// outside [cr_lo, cr_hi] the threshold is replaced by one from bisection on such counts (a handful of steps): any order of
+// the draws stays on the fast path.  (A count over the sample alone was tried first: under AR(1) with rho = 0.9 it let 3 %
+// of the rows through with twice the candidates the list holds, and sent descending rows searching on the wrong side.)
+// `t_raw`: threshold on the raw scale, replaced when a better one is found; false: none found.
+template <typename T, int VEC, bool LW>
+__device__ __forceinline__ bool wave_threshold_check(const T (&v)[kWaveSlots], const FastParams& F, const double raw_min,
+                                                     const double raw_max, double& t_raw) {
+  if (__builtin_amdgcn_readfirstlane(F.cr_hi) <= 0) return true;
+  const auto stored = [](double raw) { return LW ? (T)raw : (T)(-raw); };
+  const int c0 = count_above<T, LW>(v, stored(t_raw));
+  if (c0 >= __builtin_amdgcn_readfirstlane(F.cr_lo) && c0 <= __builtin_amdgcn_readfirstlane(F.cr_hi)) return true;
+  // (the bracket lives in vector registers: the callers' row loops are short of scalar ones)
+  double lo = (c0 > __builtin_amdgcn_readfirstlane(F.cr_hi)) ? t_raw : raw_min;
+  double hi = (c0 > __builtin_amdgcn_readfirstlane(F.cr_hi)) ? raw_max : t_raw;
+  asm volatile("" : "+v"(lo), "+v"(hi));
+#pragma unroll 1
+  for (int it = 0; it < 24; ++it) {
+    double mid = 0.5 * (lo + hi);
+    asm volatile("" : "+v"(mid));
+    const int c = count_above<T, LW>(v, stored(mid));
+    if (c > __builtin_amdgcn_readfirstlane(F.cr_hi)) lo = mid;
+    else if (c < __builtin_amdgcn_readfirstlane(F.cr_lo)) hi = mid;
+    else {
+      t_raw = uniform_d(mid);
+      return true;
+    }
+    asm volatile("" : "+v"(lo), "+v"(hi));
+  }
+  return false;  // (e.g. a block of tied draws straddles the whole band)
 }
 
 // Everything after the sweep: exact selection of the M+1 largest among the candidates, GPD fit,
@@ -885,6 +956,180 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
   }
 }
 
+// ---- split pass, everything after the sweep (production path of the one-chunk LOO kernel) --------------------------------
+// Same selection as wave_back() -- 512-bin histogram of the candidate list, suffix scan, candidates at / above the boundary
+// bin grouped by bin -- but arranged for LATENCY, because that is what this phase costs: measured on C3, the kernel streams at
+// 6.4 TB/s up to the end of the sweep and the ~750 instructions after it used to add a quarter to its run time (profiles/
+// r02_phase_ablation_1m.txt): chains of dependent LDS round trips at two waves per SIMD.  Here every stage issues all its
+// LDS operations at once: the (up to 512) candidates are read into 8 registers per lane ONCE and feed the histogram atomics,
+// the boundary test and the scatter; the two wave-wide sums are reduced under the first LDS round trip; the hand-over's
+// exponentials run as `ws_stride / 64` independent chains.  Lists longer than 512 take a second, looped batch.
+// Hands over to fit_rows_kernel (pla_fit.h): y = e^x - e^xcut of the tail in bin-grouped descending order + 6 scalars.
+template <typename SM, typename TB, int HU = 4>  // HU: 64-value blocks of the hand-over (ws_stride <= 64 HU)
+__device__ __forceinline__ void wave_select_split(const FastParams& F, SM& sm, const TB& tb, const int64_t r, const int lane_id,
+                                                  const int M, const double m, const double mn, const double s1, const double s2,
+                                                  const unsigned ncand, const int k1, const int sh, const double magic,
+                                                  const double c256, bool& slow, const int dbgs = 0) {
+  constexpr int kSa = SM::Caps::kSa;
+  constexpr int U = 8;  // candidates per lane held in registers
+  // (opaque: the addresses this phase derives from the lane number must not be computed -- and kept alive -- across the sweep)
+  int lane = lane_id;
+  asm volatile("" : "+v"(lane));
+  constexpr int kCand = SM::Caps::kCand;
+  const auto key_of = [&](double xx) { return __double2loint(fma(xx, c256, magic)); };
+  // Lanes with nothing to count or to place still execute the stage's LDS operations (straight-line code, every round trip in
+  // flight together) on a dump bin / dump slot of their OWN -- 64 lanes hammering one LDS address cost more than the
+  // branches they save.  Both live in the tail of the candidate array, which the sweep no longer needs: its 64 overflow
+  // slots (as 32-bit bins) and its per-lane dump slots.
+  unsigned* const dump_bin = reinterpret_cast<unsigned*>(&sm.cand[kCand]) + lane;
+  double* const dump_slot = &sm.cand[kCand + kWave + lane];
+  PLA_PHASE(4);
+  // ---- candidates -> registers; histogram atomics (no return value: fire and forget) -------------------------------
+  double xs[U];
+  int bx[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const unsigned c = lane + kWave * u;
+    xs[u] = sm.cand[c < ncand ? c : 0];
+  }
+  double s1_all, s2_all;
+  wave_all2<R_SUM>(s1, s2, s1_all, s2_all);  // (independent of the list: runs while the reads are in flight)
+  const auto ablate_exit = [&](int bit) {  // profiling builds: stop here, leave a tail of length 0 (not fitted)
+    if (!(dbgs & bit)) return false;
+    if (lane == 0) {
+      double* ws = F.ws_s + r * 8;
+      ws[0] = m; ws[1] = mn; ws[2] = s1_all; ws[3] = s2_all; ws[4] = 0.5; ws[5] = 0.0;
+    }
+    return true;
+  };
+  if (ablate_exit(32)) return;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const unsigned c = lane + kWave * u;
+    bx[u] = c < ncand ? (key_of(xs[u]) - k1) >> sh : kWaveBins;  // (kWaveBins: past the end of the list)
+    atomicAdd(bx[u] < kWaveBins ? &sm.hist[bx[u]] : dump_bin, 1u);
+  }
+  for (unsigned c = lane + kWave * U; c < ncand; c += kWave) atomicAdd(&sm.hist[(key_of(sm.cand[c]) - k1) >> sh], 1u);
+  wave_sync();
+  PLA_PHASE(5);
+  // ---- suffix scan over the bins (8 per lane): boundary bin of rank M ----------------------------------------------
+  int bstar = 0, C1 = 0, nbnd = 0;
+  {
+    unsigned c[8];
+    unsigned tot = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint4 h = *reinterpret_cast<const uint4*>(&sm.hist[8 * lane + 4 * i]);
+      c[4 * i] = h.x; c[4 * i + 1] = h.y; c[4 * i + 2] = h.z; c[4 * i + 3] = h.w;
+      tot += h.x + h.y + h.z + h.w;
+    }
+    unsigned pre = tot;
+    pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)tot, 0x111, 0xF, 0xF, true);   // row_shr:1
+    pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)tot, 0x112, 0xF, 0xF, true);   // row_shr:2
+    pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)tot, 0x113, 0xF, 0xF, true);   // row_shr:3
+    pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x114, 0xF, 0xE, false);  // row_shr:4, banks 1-3
+    pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x118, 0xF, 0xC, false);  // row_shr:8, banks 2-3
+    pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x142, 0xA, 0xF, false);  // row_bcast:15
+    pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x143, 0xC, 0xF, false);  // row_bcast:31
+    const unsigned all = (unsigned)__builtin_amdgcn_readlane((int)pre, kWave - 1);
+    unsigned a = all - pre;  // candidates in bins owned by higher lanes
+    int fb = -1, fc = 0, fn = 0;
+    unsigned st[8];
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+      st[i] = a;
+      if ((unsigned)M >= a && (unsigned)M < a + c[i]) {
+        fb = 8 * lane + i;
+        fc = (int)(a + c[i]);
+        fn = (int)c[i];
+      }
+      a += c[i];
+    }
+    *reinterpret_cast<uint4*>(&sm.start[8 * lane]) =
+        make_uint4(st[0] | (st[1] << 16), st[2] | (st[3] << 16), st[4] | (st[5] << 16), st[6] | (st[7] << 16));
+    const unsigned long long who = __ballot(fb >= 0);
+    const int src = __ffsll((long long)who) - 1;
+    bstar = __builtin_amdgcn_readlane(fb, src);
+    C1 = __builtin_amdgcn_readlane(fc, src);
+    nbnd = __builtin_amdgcn_readlane(fn, src);
+  }
+  wave_sync();
+  if (C1 > kSa || nbnd > kWave) {  // (more than 64 draws share the cutoff's bin: heavy ties)
+    slow = true;
+    return;
+  }
+  if (ablate_exit(64)) return;
+  PLA_PHASE(6);
+  // ---- candidates at / above the boundary bin -> sa, grouped by bin (descending bins): all the slot requests at once -----
+  unsigned old[U], st[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const bool take = bx[u] >= bstar && bx[u] < kWaveBins;
+    old[u] = atomicSub(take ? &sm.hist[bx[u]] : dump_bin, 1u);
+    st[u] = sm.start[take ? bx[u] : 0];
+    bx[u] = take ? 1 : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) *(bx[u] ? &sm.sa[st[u] + old[u] - 1u] : dump_slot) = xs[u];
+  for (unsigned c = lane + kWave * U; c < ncand; c += kWave) {  // (lists beyond 512 entries)
+    const double x = sm.cand[c];
+    const int b = (key_of(x) - k1) >> sh;
+    if (b >= bstar) sm.sa[sm.start[b] + (atomicSub(&sm.hist[b], 1u) - 1u)] = x;
+  }
+  wave_sync();
+  if (ablate_exit(128)) return;
+  PLA_PHASE(8);
+  // ---- the boundary bin: it holds the cutoff x_(S-M) itself (psis.py:135-136); its members strictly above the cutoff are
+  //      the last of the tail (psis.py:139: ties at the cutoff leave the tail) ------------------------------------------
+  const int na = C1 - nbnd;  // candidates in the bins above: all in the tail
+  const double xb = sm.sa[na + (lane < nbnd ? lane : 0)];
+  // the tail's values in the higher bins, on their way while the boundary bin is sorted out
+  double xh[HU];
+#pragma unroll
+  for (int u = 0; u < HU; ++u) {
+    const int j = lane + kWave * u;
+    xh[u] = sm.sa[j < na ? j : 0];
+  }
+  int gt = 0, ge = 0;
+  for (int j = 0; j < nbnd; ++j) {
+    const double xj = lane_value(xb, j);
+    gt += (xj > xb) ? 1 : 0;
+    ge += (xj >= xb) ? 1 : 0;
+  }
+  const int want = M - na;  // the cutoff is the (M - na)-th largest (0-based) of the boundary bin: gt <= want < ge
+  const unsigned long long isc = __ballot(lane < nbnd && gt <= want && want < ge);
+  const int src = __ffsll((long long)isc) - 1;
+  const double xcut = lane_value(xb, src);
+  const int n = na + __builtin_amdgcn_readlane(gt, src);  // draws strictly above the cutoff
+  // ---- hand-over: y = e^x - e^xcut (psis.py:147) in the candidates' order, zeros from n up to the row stride ----------
+  const int stride = F.ws_stride;
+  double* wy = F.ws_y + r * (int64_t)stride;
+  if (n > 4) {
+    const bool mine = lane < nbnd && xb > xcut;
+    const unsigned long long mm = __ballot(mine);
+    const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
+    // independent exponentials: the cutoff, the boundary bin's, HU of the higher bins'
+    double eh[HU];
+    const double e_cut = exp_tab(xcut, tb.tab);
+    const double eb = exp_tab(xb, tb.tab);
+#pragma unroll
+    for (int u = 0; u < HU; ++u) eh[u] = exp_tab(xh[u], tb.tab);
+#pragma unroll
+    for (int u = 0; u < HU; ++u) {
+      const int j = lane + kWave * u;
+      if (j < stride && (j < na || j >= n) && !(dbgs & 256)) wy[j] = j < na ? eh[u] - e_cut : 0.0;
+    }
+    if (mine && !(dbgs & 256)) wy[na + (int)pos] = eb - e_cut;
+    if (lane == 0) {
+      double* ws = F.ws_s + r * 8;
+      ws[0] = m; ws[1] = mn; ws[2] = s1_all; ws[3] = s2_all; ws[4] = e_cut; ws[5] = (double)n;
+    }
+  } else if (lane == 0) {
+    double* ws = F.ws_s + r * 8;
+    ws[0] = m; ws[1] = mn; ws[2] = s1_all; ws[3] = s2_all; ws[4] = exp_tab(xcut, tb.tab); ws[5] = (double)n;
+  }
+}
+
 // LW = false: LOO mode (input = log-likelihood, raw = -ll; outputs k-hat, loo_i, lppd_i)
 // LW = true:  weights mode (input = log ratios, raw = input; outputs k-hat and the normalised smoothed
 //             log-weights, psis.py:78-111): the row stays in its registers until the weights are stored
@@ -894,7 +1139,10 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   constexpr int EPT = kWaveSlots;
   constexpr int NQ = EPT / VEC;
   constexpr int kCand = SM::Caps::kCand, kSa = SM::Caps::kSa;  // LDS capacities of this instantiation
-  const int lane = wave_lane();
+  // (opaque per row: lane-derived masks and addresses of the later phases are then computed where they are used instead of
+  // being hoisted above the row loop, where they would sit on top of the 128 row registers)
+  int lane = wave_lane();
+  asm volatile("" : "+v"(lane));
   // parameters arrive by reference (memory): read each once into scalar registers
   const int S = __builtin_amdgcn_readfirstlane(P.n_draws);
   const int M = __builtin_amdgcn_readfirstlane(P.tail_count);
@@ -949,10 +1197,19 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     }
     t1 = fma((double)hi_i, spread * (1.0 / 1048576.0), lo0) - m;
   }
+  // pads: from here on the slots past the row hold ll = -mn (raw = mn, x = -R: the smallest value of the row) instead of copies
+  // of the lane's first vector -- never at or above a threshold, so the counts below see real draws only
+  pad_tail<T, VEC, NQ - 1, true>(v, qfull, qrem, LW ? (T)mn : (T)(-mn));
+  bool thr_ok = true;
+  if (m - mn < kWaveMaxRange) {  // (rows with non-finite draws or too wide a range go to the general kernel anyway)
+    double t_raw = t1 + m;
+    thr_ok = wave_threshold_check<T, VEC, LW>(v, F, mn, m, t_raw);
+    t1 = t_raw - m;
+  }
   // +-inf in the row makes R inf/NaN; a NaN draw is ignored by v_max here, poisons s1 in the sweep
   // and is caught by the finiteness test at the end: both land on the general kernel
   PLA_PHASE(1);
-  bool slow = !(R < kWaveMaxRange) || !(t1 < 0.0);
+  bool slow = !(R < kWaveMaxRange) || !(t1 < 0.0) || !thr_ok;
   // constants every later phase uses, pinned in registers by hand (MachineLICM is off for this file:
   // the compiler would otherwise re-materialise them inside every loop)
   double magic = kMagic, c256 = kC256;
@@ -964,6 +1221,9 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   if (kpad >= k1) slow = true;               // pads would be counted as candidates
   double khat = INF, loo = 0.0, lppd = 0.0;
   bool streamed = false;  // next row's loads already issued (inside the sweep)
+#if PLA_WAVE_ABLATE
+  int why_cand = 0;
+#endif
   if (dbgs & 16) {
     loo = t1 + R;  // ablation: statistics and threshold only
   } else if (!slow) {
@@ -976,9 +1236,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
 #pragma unroll
       for (int i = 0; i < kWaveBins / (4 * kWave); ++i) *reinterpret_cast<uint4*>(&sm.hist[4 * (lane + kWave * i)]) = z4;
     }
-    // pads: rewrite invalid vectors to ll = -mn  (raw = mn, x = -R)
-    const T padv = LW ? (T)mn : (T)(-mn);
-    pad_tail<T, VEC, NQ - 1, true>(v, qfull, qrem, padv);
     wave_sync();
     // ---- 2. sweep: e^x and e^-x of every draw from one range reduction + histogram of candidates ----
     // (e^(ll - max ll) = e^-R * e^-x; the row constant e^-R is applied to the sum, in log space)
@@ -1096,6 +1353,11 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       lppd = s2;
     } else if ((int)ncand < M + 1 || ncand > (unsigned)kCand) {
       slow = true;  // the speculative threshold missed (too few / too many draws above it)
+#if PLA_WAVE_ABLATE
+      why_cand = (int)ncand < M + 1 ? 1 : 2;
+#endif
+    } else if constexpr (SPLIT && kFitSorts && !LW) {
+      wave_select_split(F, sm, tb, r, lane, M, m, mn, s1, s2, ncand, k1, sh, magic, c256, slow, dbgs);
     } else {
       wave_back<T, VEC, LW, SM, TB, SPLIT>(P, sm, tb, r, v, lane, S, M, mestM, logS, dbgs, m, mn, R, 0.0, s1, s2, ncand, k1, sh,
                                            magic, c256, qfull, qrem, slow, khat, loo, lppd, &F);
@@ -1109,6 +1371,17 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     if (slow) {
       const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
       F.slow_list[idx] = (unsigned)r;
+#if PLA_WAVE_ABLATE
+      {  // why the row left the fast path (profiling builds: PLA_PRINT_REASONS)
+        int why = 7;  // selection / outputs
+        if (!(R < kWaveMaxRange)) why = 0;
+        else if (!thr_ok) why = 1;
+        else if (!(t1 < 0.0)) why = 2;
+        else if (kpad >= k1) why = 3;
+        else if (why_cand) why = 3 + why_cand;  // 4: too few candidates, 5: too many
+        atomicAdd(&F.counters[8 + why], 1ull);
+      }
+#endif
       if constexpr (SPLIT) F.ws_s[r * 8 + 5] = -1.0;  // tail length -1: tells the fit kernel that this observation is on the list
     } else if constexpr (!SPLIT) {
       if (P.diag) P.diag[r] = khat;

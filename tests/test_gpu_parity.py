@@ -533,7 +533,8 @@ def test_loo_i_front(eng):
 
 
 def test_observation_fastest_device_layout(eng):
-    """(S, N) buffer viewed as (N, S) -- the ArviZ-native layout: transposed block by block inside the library, then the fast path."""
+    """(S, N) buffer viewed as (N, S) -- the ArviZ-native layout, read in place by the lane-per-observation kernels (LOO) or
+    transposed block by block inside the library (weights)."""
     import torch
 
     rng = np.random.default_rng(21)
@@ -553,8 +554,9 @@ def test_observation_fastest_device_layout(eng):
 @pytest.mark.parametrize("N,S,dt", [(500, 4000, np.float64), (130, 1000, np.float32), (67, 258, np.float64), (2, 4096, np.float64),
                                     (1000, 8000, np.float32)])
 def test_observation_fastest_ingestion(eng, N, S, dt):
-    """The library's own transposing ingestion (64 x 64 tiles): ragged tile edges, both dtypes, LOO and WAIC passes give the
-    bits of the draws-fastest copy."""
+    """Observations-fastest device matrices: the WAIC pass (transposing ingestion, 64 x 16 tiles: ragged tile edges, both
+    dtypes) gives the bits of the draws-fastest copy; the LOO pass reads such a matrix in place with one lane per observation
+    (pla_col.h) where its shape allows, and then agrees to rounding (another order of summation), else bitwise as well."""
     import torch
 
     rng = np.random.default_rng(N + S)
@@ -564,8 +566,14 @@ def test_observation_fastest_ingestion(eng, N, S, dt):
     view = torch.from_numpy(np.ascontiguousarray(ll.T)).cuda().T   # (N, S) view of an (S, N) buffer
     assert view.stride(0) == 1 and view.stride(1) == N
     a, b = eng.psis_loo(view, M, "psis", 1.0, 0.7), eng.psis_loo(rowmajor, M, "psis", 1.0, 0.7)
+    column_path = S >= 512 and M <= 250
     for key in ("diag", "loo_i", "lppd_i", "agg"):
-        np.testing.assert_array_equal(a[key].cpu().numpy(), b[key].cpu().numpy(), err_msg=key)
+        if column_path:
+            n_cmp = 7 if key == "agg" else None
+            np.testing.assert_allclose(a[key].cpu().numpy()[:n_cmp], b[key].cpu().numpy()[:n_cmp], rtol=1e-11, atol=1e-12, err_msg=key)
+        else:
+            np.testing.assert_array_equal(a[key].cpu().numpy(), b[key].cpu().numpy(), err_msg=key)
+    assert a["agg"][7].item() == 0
     wa, wb = eng.waic(view, 1.0), eng.waic(rowmajor, 1.0)
     for key in ("lppd_i", "var_i", "waic_i", "agg"):
         np.testing.assert_array_equal(wa[key].cpu().numpy(), wb[key].cpu().numpy(), err_msg=key)
@@ -663,8 +671,9 @@ def test_heavy_tails_near_the_cancellation_guard(eng):
 
 
 def test_ingestion_in_many_blocks():
-    """The transposing ingestion with 1 MB blocks (32 rows each at S = 4000): block boundaries, output offsets and the
-    hand-over workspace of the split pass sized per block.  Own process: the block size is read once per process."""
+    """The transposing ingestion (PLA_INGEST_TRANSPOSE=1: the LOO pass too) with 1 MB blocks (32 rows each at S = 4000): block
+    boundaries, output offsets and the hand-over workspace of the split pass sized per block.  Own process: both knobs are
+    read once per process."""
     import subprocess
     import sys
 
@@ -691,6 +700,37 @@ h1 = eng.psis_loo(np.ascontiguousarray(ll.T).T, 190, "psis", 1.0, 0.7)   # host 
 assert np.array_equal(h1["loo_i"], b["loo_i"].cpu().numpy())
 print("blocks ok")
 """ % ROOT
-    env = dict(os.environ, PLA_INGEST_BLOCK_MB="1")
+    env = dict(os.environ, PLA_INGEST_BLOCK_MB="1", PLA_INGEST_TRANSPOSE="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "blocks ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_column_kernels_on_observation_fastest_matrices(eng):
+    """pla_col.h: one lane per observation on an (S, N) buffer -- several blocks of observations (> 262 144), a ragged last
+    workgroup, heavy-tailed rows, rows with non-finite draws (general kernel through the strided view), against the
+    draws-fastest pass and the oracle."""
+    import torch
+
+    N, S = 300_011, 512
+    t = torch.empty((N, S), dtype=torch.float32, device="cuda")
+    eng.fill_synthetic(t, seed=99, k_lo=0.05, k_hi=1.1)
+    t[7, 100] = float("nan")
+    t[70_000, 3] = float("inf")
+    t[262_200] = -3.0  # a constant row: every weight equal, k = inf (psis.py:142-144 through ties at the cutoff)
+    M = orc.tail_count(S, 1.0)
+    view = t.T.contiguous().T  # (N, S) view of an (S, N) buffer: observations fastest
+    assert view.stride(0) == 1
+    a = eng.psis_loo(view, M, "psis", 1.0, 0.7)
+    b = eng.psis_loo(t, M, "psis", 1.0, 0.7)
+    torch.cuda.synchronize()
+    for key in ("diag", "loo_i", "lppd_i"):
+        x, y = a[key].cpu().numpy(), b[key].cpu().numpy()
+        assert np.array_equal(np.isnan(x), np.isnan(y)) and np.array_equal(np.isinf(x), np.isinf(y)), key
+        ok = np.isfinite(y)
+        np.testing.assert_allclose(x[ok], y[ok], rtol=1e-10, atol=1e-11, err_msg=key)
+    assert a["agg"][7].item() <= 0.01 * N
+    idx = np.r_[0:40, 7, 70_000, 262_140:262_210, N - 30:N]
+    ref = orc.loo_arrays(t[torch.from_numpy(idx).cuda()].cpu().numpy().astype(np.float64), 1.0)
+    close(a["diag"].cpu().numpy()[idx], ref["khat"], what="khat")
+    close(a["loo_i"].cpu().numpy()[idx], ref["loo_i"], what="loo_i")
+    close(a["lppd_i"].cpu().numpy()[idx], ref["lppd_i"], what="lppd_i")

@@ -68,17 +68,22 @@ def make_rows(kind, n, s, rng, chains=4):
 
 
 # (kind, S, dtype, bound on the fraction of rows handed to the general kernel)
+# Measured (profiles/r02_handover_rates_*.jsonl).  Round 1's threshold -- group maxima over the row's first 512 draws -- handed
+# over 100 % of sorted rows, 13 % of AR(1) rows and 40 % of chain-major AR(1) rows with per-chain offsets.  Now the sample is
+# spread over the row (bit-reversed vector order) and the threshold is verified against an EXACT count of the register
+# block before the sweep, with bisection on such counts when it fails: every one-chunk case below stays on the fast path.
 CASES = [
     ("iid", 4000, np.float64, 0.002),
     ("ascending", 4000, np.float64, 0.002),
     ("descending", 4000, np.float64, 0.002),
-    ("ar1", 4000, np.float64, 0.01),
-    ("chains_ar1", 4000, np.float64, 0.01),
-    ("chains_scale", 4000, np.float64, 0.01),
-    ("chains_ar1", 2000, np.float64, 0.02),
-    # long rows: the threshold sample is spread over the first 4096 draws only (single read of the row)
-    ("ar1", 20000, np.float32, 0.02),
-    ("chains_ar1", 8000, np.float64, 0.05),
+    ("ar1", 4000, np.float64, 0.002),
+    ("chains_ar1", 4000, np.float64, 0.002),
+    ("chains_scale", 4000, np.float64, 0.002),
+    ("chains_ar1", 2000, np.float64, 0.002),
+    # long rows are read ONCE in chunks of 4096 draws, so the threshold can only know the first chunk: exact for that
+    # chunk (autocorrelation inside it no longer matters: 79 % -> 3 %), blind to what later chains do differently
+    ("ar1", 20000, np.float32, 0.06),
+    ("chains_ar1", 8000, np.float64, 0.30),
 ]
 
 
