@@ -202,6 +202,22 @@ int pla_e_loo(pla_engine *eng, const void *x, const void *log_weights, const voi
               int mem_space, void *stream, double *mean, double *variance, double *k_mean, double *k_var,
               double *k_ratio);
 
+/*
+ * pla_e_loo_quantiles -- PSIS-weighted quantiles of the draws (e_loo(type="quantile")).
+ * Replaces `_compute_weighted_quantiles` (e_loo.py:468-515: the `np.ndindex` loop over observations and probabilities) and
+ * `_weighted_quantile` (534-554): argsort + cumulative normalised weights + linear interpolation between the two draws that
+ * bracket `prob`; np.quantile(x, prob) when the weights are all close (536-537).  No sort on the device: a weighted radix
+ * selection per (observation, prob) -- see csrc/pla_eloo.h.
+ *
+ *   x, log_weights  (n_obs, n_draws), same dtype and strides, as in pla_e_loo
+ *   probs           [n_probs] HOST array (whatever mem_space says), each strictly between 0 and 1 (e_loo.py:158-159)
+ *   out             [n_obs][n_probs] double, in the memory space of the matrices
+ * The Pareto k of this type is pla_e_loo's k_ratio (e_loo.py:229-230).
+ */
+int pla_e_loo_quantiles(pla_engine *eng, const void *x, const void *log_weights, int dtype, int64_t n_obs,
+                        int64_t n_draws, int64_t stride_obs, int64_t stride_draw, const double *probs,
+                        int64_t n_probs, int mem_space, void *stream, double *out);
+
 /* Timing of the dominant kernel, measured with hipEvents on the launch stream.
  * enable != 0 brackets every main-kernel launch with events; pla_engine_kernel_ms returns the
  * accumulated milliseconds and launch count since the last call (it synchronises the events). */

@@ -18,7 +18,7 @@ ABI_VERSION = 2
 SYMBOLS = (
     "pla_abi_version", "pla_last_error", "pla_device_count", "pla_engine_create", "pla_engine_destroy",
     "pla_tail_count", "pla_psis_loo", "pla_importance_weights", "pla_reduce_pointwise", "pla_waic",
-    "pla_psis_loo_rows", "pla_waic_rows", "pla_e_loo",
+    "pla_psis_loo_rows", "pla_waic_rows", "pla_e_loo", "pla_e_loo_quantiles",
     "pla_engine_set_frozen", "pla_engine_set_timing", "pla_engine_kernel_ms", "pla_engine_first_kernel_ms", "pla_fill_synthetic",
 )
 
@@ -70,6 +70,7 @@ def load_library():
     lib.pla_psis_loo_rows.argtypes = [vp, vp, ci, i64, i64, i64, i64, vp, i64, ci, i64, dbl, dbl, ci, vp, vp, vp, vp, vp]
     lib.pla_waic_rows.argtypes = [vp, vp, ci, i64, i64, i64, i64, vp, i64, dbl, ci, vp, vp, vp, vp, vp]
     lib.pla_e_loo.argtypes = [vp, vp, vp, vp, ci, i64, i64, i64, i64, i64, ci, vp, vp, vp, vp, vp, vp]
+    lib.pla_e_loo_quantiles.argtypes = [vp, vp, vp, ci, i64, i64, i64, i64, vp, i64, ci, vp, vp]
     lib.pla_engine_set_frozen.argtypes = [vp, ci]
     lib.pla_engine_set_timing.argtypes = [vp, ci]
     lib.pla_engine_kernel_ms.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]

@@ -68,6 +68,8 @@ struct pla_engine {
   size_t d_ws_bytes = 0;
   void* d_col = nullptr;   // observations-fastest LOO (pla_col.h): candidate lists + scalars of one block of observations
   size_t d_col_bytes = 0;
+  void* d_probs = nullptr;  // quantile levels of pla_e_loo_quantiles
+  size_t d_probs_bytes = 0;
   void* d_rows = nullptr;  // clamped copy of a caller's device row-index list
   void* d_slab = nullptr;  // host path, observations-fastest input: (n_draws, block of observations) slab before the transpose
   size_t d_slab_bytes = 0;
@@ -260,6 +262,7 @@ int pla_engine_destroy(pla_engine* e) {
   if (e->d_ws) (void)hipFree(e->d_ws);
   if (e->d_rows) (void)hipFree(e->d_rows);
   if (e->d_col) (void)hipFree(e->d_col);
+  if (e->d_probs) (void)hipFree(e->d_probs);
   if (e->d_slab) (void)hipFree(e->d_slab);
   for (int i = 0; i < pla_engine::kTimingRing; ++i) {
     if (e->ev0[i]) (void)hipEventDestroy(e->ev0[i]);
@@ -903,6 +906,59 @@ int pla_e_loo(pla_engine* eng, const void* x, const void* log_weights, const voi
     for (int k = 0; k < 5; ++k)
       if (out[k]) PLA_HIP(hipMemcpyAsync(out[k] + r0, d + k * nr, (size_t)nr * sizeof(double), hipMemcpyDeviceToHost, s));
     PLA_HIP(hipStreamSynchronize(s));  // the staging buffers are reused by the next block
+  }
+  return PLA_OK;
+}
+
+int pla_e_loo_quantiles(pla_engine* eng, const void* x, const void* log_weights, int dtype, int64_t n_obs, int64_t n_draws,
+                        int64_t stride_obs, int64_t stride_draw, const double* probs, int64_t n_probs, int mem_space, void* stream,
+                        double* out) {
+  if (!eng) return fail(PLA_ERR_ARG, "engine is NULL");
+  if (dtype != PLA_F64 && dtype != PLA_F32) return fail(PLA_ERR_ARG, "dtype must be PLA_F64 or PLA_F32");
+  if (mem_space != PLA_HOST && mem_space != PLA_DEVICE) return fail(PLA_ERR_ARG, "bad mem_space");
+  if (n_obs < 0 || n_probs < 0) return fail(PLA_ERR_ARG, "negative size");
+  if (n_obs > 0 && (!x || !log_weights)) return fail(PLA_ERR_ARG, "x / log_weights is NULL");
+  if (n_obs > 0 && n_probs > 0 && (!probs || !out)) return fail(PLA_ERR_ARG, "probs / out is NULL");
+  if (n_draws < 1 || n_draws > (int64_t)1 << 30) return fail(PLA_ERR_ARG, "n_draws out of range");
+  if (stride_draw <= 0 || stride_obs < 0) return fail(PLA_ERR_ARG, "bad strides");
+  for (int64_t i = 0; i < n_probs; ++i)
+    if (!(probs[i] > 0.0 && probs[i] < 1.0)) return fail(PLA_ERR_ARG, "probs must be between 0 and 1");  // e_loo.py:158-159
+  if (n_obs == 0 || n_probs == 0) return PLA_OK;
+  EngineCall call(eng);
+  PLA_HIP(hipSetDevice(eng->device));
+  hipStream_t s = (hipStream_t)stream;
+  int rc = grow(&eng->d_probs, &eng->d_probs_bytes, (size_t)n_probs * sizeof(double));
+  if (rc) return rc;
+  PLA_HIP(hipMemcpyAsync(eng->d_probs, probs, (size_t)n_probs * sizeof(double), hipMemcpyHostToDevice, s));
+  PLA_HIP(hipStreamSynchronize(s));  // (the caller's probs array may go away after the call)
+  const double* dp = (const double*)eng->d_probs;
+  if (mem_space == PLA_DEVICE) {
+    PLA_HIP(pla::launch_e_loo_quantiles(x, log_weights, dtype, n_obs, (int)n_draws, stride_obs, stride_draw, dp, (int)n_probs, out, s));
+    return PLA_OK;
+  }
+  if (stride_draw != 1) return fail(PLA_ERR_UNSUPPORTED, "PLA_HOST input needs stride_draw == 1");
+  const size_t esz = dtype == PLA_F64 ? 8 : 4;
+  const size_t row_bytes = (size_t)n_draws * esz;
+  int64_t rows_per_chunk = (int64_t)(((size_t)1 << 29) / row_bytes);
+  if (rows_per_chunk < 1) rows_per_chunk = 1;
+  if (rows_per_chunk > n_obs) rows_per_chunk = n_obs;
+  rc = grow(&eng->d_in, &eng->d_in_bytes, (size_t)rows_per_chunk * row_bytes);
+  if (!rc) rc = grow(&eng->d_lw, &eng->d_lw_bytes, (size_t)rows_per_chunk * row_bytes);
+  if (rc) return rc;
+  {
+    size_t have_b = eng->d_pw_elems * sizeof(double);
+    rc = grow((void**)&eng->d_pw, &have_b, (size_t)(rows_per_chunk * n_probs) * sizeof(double));
+    eng->d_pw_elems = have_b / sizeof(double);
+    if (rc) return rc;
+  }
+  for (int64_t r0 = 0; r0 < n_obs; r0 += rows_per_chunk) {
+    const int64_t nr = (n_obs - r0 < rows_per_chunk) ? (n_obs - r0) : rows_per_chunk;
+    const size_t off = (size_t)r0 * stride_obs * esz, pitch = (size_t)stride_obs * esz;
+    PLA_HIP(hipMemcpy2DAsync(eng->d_in, row_bytes, (const char*)x + off, pitch, row_bytes, (size_t)nr, hipMemcpyHostToDevice, s));
+    PLA_HIP(hipMemcpy2DAsync(eng->d_lw, row_bytes, (const char*)log_weights + off, pitch, row_bytes, (size_t)nr, hipMemcpyHostToDevice, s));
+    PLA_HIP(pla::launch_e_loo_quantiles(eng->d_in, eng->d_lw, dtype, nr, (int)n_draws, n_draws, 1, dp, (int)n_probs, eng->d_pw, s));
+    PLA_HIP(hipMemcpyAsync(out + r0 * n_probs, eng->d_pw, (size_t)(nr * n_probs) * sizeof(double), hipMemcpyDeviceToHost, s));
+    PLA_HIP(hipStreamSynchronize(s));
   }
   return PLA_OK;
 }

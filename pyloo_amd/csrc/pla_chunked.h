@@ -202,7 +202,8 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
       // split pass: selection here, fit / smoothing / outputs in fit_rows_kernel (16 lanes per observation, pla_fit.h).
       // The second sum is brought to the true shift as well: e^-x = e^-x' e^(m - m')  (R < 690 keeps it finite)
       s2 *= exp_tab(delta, tb.tab);
-      wave_select_split<SM, TB, (SM::Caps::kMaxTail + 63) / 64>(F, sm, tb, r, lane, M, m, mn, s1, s2, ncand, k1, sh, magic, c256, slow);
+      wave_select_split<SM, TB, (SM::Caps::kMaxTail + 63) / 64>(F, sm, tb, r, lane, M, m, mn, s1, s2, ncand, k1, sh, magic, c256, slow,
+                                                                CandInLds<SM>{sm});
     } else {
       wave_back<T, VEC, LW, SM, TB>(P, sm, tb, r, v, lane, S, M, mestM, logS, dbgs, m, mn, R, delta, s1, s2, ncand, k1, sh,
                                     magic, c256, nvl / kWave, nvl % kWave, slow, khat, loo, lppd);

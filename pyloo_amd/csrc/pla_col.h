@@ -28,6 +28,23 @@
 
 namespace pla {
 
+#ifndef PLA_COL_U
+#define PLA_COL_U 8        // draws per batch; two batches in flight per lane
+#endif
+#ifndef PLA_COL_WAVES
+#define PLA_COL_WAVES 3    // waves per SIMD the sweep is compiled for
+#endif
+#ifndef PLA_COL_ILP
+#define PLA_COL_ILP 4      // draws the scheduler may interleave
+#endif
+#ifndef PLA_COL_STORE_AUX
+#define PLA_COL_STORE_AUX 0   // cache policy of the candidate stores
+#endif
+#ifndef PLA_COL_FLUSH
+#define PLA_COL_FLUSH 8       // candidates per store burst: 8 x 8 bytes = half a cache line
+#endif
+constexpr int kColFlush = PLA_COL_FLUSH;
+constexpr int kColRing = 2 * kColFlush;  // staging ring per lane (at most kColFlush - 1 + 4 entries wait between two checks)
 constexpr int kColSample = 512;   // draws in the pre-pass: 64 groups of 8
 constexpr int kColCap = 1024;     // candidate list capacity per observation (doubles)
 
@@ -37,19 +54,40 @@ struct ColParams {
   int n_draws;
   int64_t ld;          // elements between consecutive draws
   int kq;              // the threshold has kq of the 64 group maxima below it
-  double* cand;        // [n_obs][kColCap] raw values at or above the threshold
-  double* scal;        // [n_obs][8]: m', max raw, min raw, sum e^x', sum e^-x', number of candidates (uncapped), -, -
+  double* cand;        // [n_obs][kColCap] log-likelihoods of the draws whose raw = -ll is at or above the threshold
+  double* scal;        // [n_obs][8]: m', max raw, min raw, sum e^x', sum e^-x', number of candidates (uncapped), threshold, -
 };
 
+// draw `u` of a batch: the batch's first draw is the base of the descriptor, u * ld * sizeof(T) rides in a scalar offset and
+// the lane's observation in the ONE vector offset all loads of the kernel share -- no 64-bit address per load in vector
+// registers (sixteen of them cost 32 registers and spilled)
 template <typename T>
-__global__ __launch_bounds__(256) void col_sweep_kernel(ColParams P) {
+__device__ __forceinline__ T col_load(const __amdgpu_buffer_rsrc_t rs, const int voff, const int soff) {
+  if constexpr (sizeof(T) == 8) {
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    const v2i t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, PLA_LOAD_AUX);
+    return (T)__hiloint2double(t[1], t[0]);
+  } else {
+    return (T)__int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, PLA_LOAD_AUX));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, PLA_COL_WAVES) void col_sweep_kernel(ColParams P) {
   __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];
+  // candidates are staged here, per lane, and leave for the workspace kColFlush at a time.  (Appending them one by one --
+  // 8-byte stores, each to another cache line, ten draws apart -- kept 262 144 partly written lines open against 4 MB of
+  // L2 per XCD and doubled the kernel's run time.)  Per lane: a ring of 2 kColFlush entries + a dump slot for draws that are
+  // no candidates (so that the append needs no branch) + one entry of padding that keeps the 16-byte alignment.
+  __shared__ __attribute__((aligned(16))) double stage[256][kColRing + 2];
   for (int j = threadIdx.x; j < kTabN; j += 256) exp_table_entry(tab, j);
   __syncthreads();
   const int S = P.n_draws;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = i < P.n_obs;
   const T* col = reinterpret_cast<const T*>(P.in) + (live ? i : P.n_obs - 1);  // (idle lanes re-read the last observation)
+  const int voff = (int)((live ? i : P.n_obs - 1) * (int64_t)sizeof(T));            // this lane's byte offset inside a draw
+  const int64_t draw_bytes = P.ld * (int64_t)sizeof(T);
   const double INF = pinf();
 
   // ---- pre-pass: 64 group maxima over 512 draws spread over the row; group g holds the samples g, g + 64, ... ----------
@@ -60,12 +98,18 @@ __global__ __launch_bounds__(256) void col_sweep_kernel(ColParams P) {
 #pragma unroll 1
   for (int k = 0; k < kColSample / 64; ++k) {
 #pragma unroll
-    for (int g = 0; g < 64; ++g) {
-      const int s = (int)(((int64_t)(k * 64 + g) * S) / kColSample);
-      const double raw = -(double)col[(int64_t)s * P.ld];
-      mp = fmax(mp, raw);
-      // rounded up: the threshold may only err towards FEWER candidates by what one float ulp is worth
-      gm[g] = fmaxf(gm[g], __double2float_ru(raw));
+    for (int g0 = 0; g0 < 64; g0 += 16) {  // 16 loads in flight at a time (64 would need 128 registers for the draws alone)
+      T v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = col[(((int64_t)(k * 64 + g0 + j) * S) / kColSample) * P.ld];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const double raw = -(double)v[j];
+        mp = fmax(mp, raw);
+        // rounded up: the threshold may only err towards FEWER candidates by what one float ulp is worth
+        gm[g0 + j] = fmaxf(gm[g0 + j], __double2float_ru(raw));
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   float lo = gm[0], hi = gm[0];
@@ -85,19 +129,26 @@ __global__ __launch_bounds__(256) void col_sweep_kernel(ColParams P) {
   }
   const double t_raw = (double)hi;
 
-  // ---- the pass: every draw of the observation, 8 loads in flight per lane -----------------------------------------
-  double mx = -INF, mn = INF, s1 = 0.0, s2 = 0.0;
-  int cnt = 0;
-  double* list = P.cand + (live ? i : 0) * (int64_t)kColCap;
+  // ---- the pass: every draw of the observation ------------------------------------------------------------------------
+  double nmn = INF, nmx = -INF, s1 = 0.0, s2 = 0.0;  // min / max of ll = -(max / min of raw)
+  int cnt = 0, flushed = 0;  // candidates seen / written to the workspace (a multiple of kColFlush)
+  double* const mine = stage[threadIdx.x];
+  // (the lists of this launch's observations: at most 262 144 x 8 KB = 2 GB, inside one descriptor's 32-bit range)
+  const __amdgpu_buffer_rsrc_t rs_list = __builtin_amdgcn_make_buffer_rsrc(
+      P.cand, 0, (int)(unsigned)(((P.n_obs * (int64_t)kColCap * 8) > 0xfffffff0ll) ? 0xfffffff0ll : P.n_obs * (int64_t)kColCap * 8), 0x00020000);
+  const int list_off = (int)((live ? i : 0) * (int64_t)kColCap * 8);
   const char* tabc = reinterpret_cast<const char*>(tab);
-  constexpr int U = 8;
+  constexpr int U = PLA_COL_U;
   int c4096 = 4096, cm4096 = -4096, four = 4;
   asm volatile("" : "+s"(c4096), "+s"(cm4096));
   asm volatile("" : "+v"(four));
-  const auto one = [&](double raw) {
-    mx = fmax(mx, raw);
-    mn = fmin(mn, raw);
-    const double x = raw - mp;                       // psis.py:134 about the provisional shift
+  // (`ll` = the stored log-likelihood; raw = -ll is never materialised: the negation rides in the instructions' operand
+  // modifiers, and the candidate lists hold ll as well)
+  const double nmp = -mp, nt_raw = -t_raw;
+  const auto one = [&](double ll) {
+    nmn = fmin(nmn, ll);                             // -max raw
+    nmx = fmax(nmx, ll);                             // -min raw
+    const double x = nmp - ll;                       // raw - m': psis.py:134 about the provisional shift
     const double t = fma(x, kC256, kMagic);
     const int k = __double2loint(t);                 // round(x * 256 / ln 2)
     const int4 tt = *reinterpret_cast<const int4*>(tabc + byte0_shl(k, four));  // 16 * (k & 255)
@@ -107,32 +158,94 @@ __global__ __launch_bounds__(256) void col_sweep_kernel(ColParams P) {
     const double O = fma(1.66666666666666666667e-01, r2, 1.0);
     s1 = fma(__hiloint2double(mad_i24(k, c4096, tt.y), tt.x), fma(rr, O, E), s1);
     s2 = fma(__hiloint2double(mad_i24(k, cm4096, tt.w), tt.z), fma(-rr, O, E), s2);
-    if (raw >= t_raw) {
-      if (cnt < kColCap && live) list[cnt] = raw;
-      ++cnt;
+    // candidate: into this lane's staging ring, without control flow (everything else goes to the lane's dump slot)
+    const bool cand = ll <= nt_raw;                  // raw >= threshold
+    mine[cand ? (cnt & (kColRing - 1)) : kColRing] = ll;
+    cnt += cand ? 1 : 0;
+  };
+  // kColFlush staged candidates -> the observation's list, when there are that many (called every fourth draw: at most four
+  // arrive in between, so the ring never overflows).  Bounds-checked buffer stores: what must not be written -- nothing to
+  // flush yet, list full, idle lane -- gets an offset past the end of the descriptor, which the hardware drops.
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const auto flush4 = [&]() {
+    const bool go = cnt - flushed >= kColFlush;
+    const bool wr = go & (flushed + kColFlush <= kColCap) & live;  // (bitwise: no short-circuit branches inside the sweep)
+    const int off = wr ? list_off + 8 * flushed : (int)0xffffff00;
+    const double* src = &mine[flushed & (kColRing - 1)];  // (flushed is a multiple of kColFlush: no wrap inside a burst)
+#pragma unroll
+    for (int q = 0; q < kColFlush / 2; ++q)
+      __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4i*>(src + 2 * q), rs_list, off, 16 * q, PLA_COL_STORE_AUX);
+    flushed += go ? kColFlush : 0;
+  };
+  // Two batches of U draws per lane: the loads of batch b + 1 are in flight while batch b is computed (each wave keeps
+  // 2 U x 512 bytes of HBM reads outstanding: with ~12 waves per CU that is the 100+ KB per CU the HBM latency asks for --
+  // with one batch of 8 the kernel ran at 2.8 TB/s, waiting 5 us for every 0.5 us of arithmetic)
+  T buf[2][U];
+  const int nb = S / U;  // whole batches
+  const auto fetch = [&](T (&dst)[U], int b) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(P.in) + (int64_t)b * U * draw_bytes), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < U; ++u) dst[u] = col_load<T>(rs, voff, (int)(u * draw_bytes));
+  };
+  const auto work = [&](const T (&src)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      one((double)src[u]);
+      if (u % 4 == 3) flush4();
+      // (a few draws interleave -- the table read of one under the arithmetic of the others -- but not all sixteen: the
+      // scheduler would otherwise start every draw of the batch at once and spill)
+      if (u % PLA_COL_ILP == PLA_COL_ILP - 1) __builtin_amdgcn_sched_barrier(0);
     }
   };
-  int s = 0;
+  if (nb > 0) fetch(buf[0], 0);
+  int b = 0;
 #pragma unroll 1
-  for (; s + U <= S; s += U) {
-    T v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(col + (int64_t)(s + u) * P.ld);
-#pragma unroll
-    for (int u = 0; u < U; ++u) one(-(double)v[u]);
+  for (; b + 2 <= nb; b += 2) {
+    fetch(buf[1], b + 1);
+    work(buf[0]);
+    if (b + 2 < nb) fetch(buf[0], b + 2);
+    work(buf[1]);
   }
-  for (; s < S; ++s) one(-(double)col[(int64_t)s * P.ld]);
+  if (b < nb) work(buf[0]);  // an odd last batch (already fetched)
+  for (int s = nb * U; s < S; ++s) {
+    one((double)col[(int64_t)s * P.ld]);
+    flush4();
+  }
+  flush4();
+  for (int j = flushed; j < cnt && j < kColCap; ++j)  // the last, fewer than a burst, one by one
+    if (live) P.cand[i * (int64_t)kColCap + j] = mine[j & (kColRing - 1)];
   if (live) {
     double* o = P.scal + i * 8;
-    o[0] = mp; o[1] = mx; o[2] = mn; o[3] = s1; o[4] = s2; o[5] = (double)cnt;
+    o[0] = mp; o[1] = -nmn; o[2] = -nmx; o[3] = s1; o[4] = s2; o[5] = (double)cnt; o[6] = t_raw;
   }
 }
 
-// One wavefront per observation: the candidate list -> LDS, then the split pass's selection.  Workgroups of 4 independent
-// waves sharing the exponential table.
+// One wavefront per observation: the split pass's selection on the candidate list, read where it lies (no LDS copy: the
+// scratch per wave is the histogram, the bin offsets and the bin-grouped tail: 6 KB, so 24 waves fit a CU and hide the
+// latencies this phase consists of).  Workgroups of 4 independent waves sharing the exponential table.
+template <class CAP>
+struct ColSmem {
+  using Caps = CAP;
+  unsigned hist[kWaveBins];
+  unsigned short start[kWaveBins];
+  double sa[CAP::kSa + 4];
+  double dump_slot[kWave];
+  unsigned dump_bin[kWave];
+};
+template <class SM>
+struct CandInList {  // x = raw - max raw with the reference's single rounding (psis.py:134); the list holds ll = -raw
+  const double* list;
+  double m;
+  SM& sm;
+  __device__ __forceinline__ double at(unsigned c) const { return (-list[c]) - m; }
+  __device__ __forceinline__ unsigned* dump_bin(int lane) const { return &sm.dump_bin[lane]; }
+  __device__ __forceinline__ double* dump_slot(int lane) const { return &sm.dump_slot[lane]; }
+};
+
 template <class CAP>
 __global__ __launch_bounds__(kWave * 4) void col_select_kernel(ColParams P, FastParams F, int tail_count) {
-  using SM = WaveSmemT<CAP>;
+  using SM = ColSmem<CAP>;
   struct TB { double tab[2 * kTabN]; };
   __shared__ __attribute__((aligned(16))) SM scratch[4];
   __shared__ __attribute__((aligned(16))) TB tb;
@@ -145,7 +258,7 @@ __global__ __launch_bounds__(kWave * 4) void col_select_kernel(ColParams P, Fast
   for (int64_t r = (int64_t)blockIdx.x * 4 + wv; r < P.n_obs; r += (int64_t)gridDim.x * 4) {
     const double* sc = P.scal + r * 8;
     const double mp = uniform_d(sc[0]), m = uniform_d(sc[1]), mn = uniform_d(sc[2]);
-    const double s1p = uniform_d(sc[3]), s2p = uniform_d(sc[4]);
+    const double s1p = uniform_d(sc[3]), s2p = uniform_d(sc[4]), t_raw = uniform_d(sc[6]);
     const int ncand = (int)uniform_d(sc[5]);
     const double R = m - mn, delta = m - mp;  // delta >= 0: the sample's maximum against the row's
     bool slow = !(R < kWaveMaxRange) || ncand < M + 1 || ncand > CAP::kCand || ncand > kColCap || !(fabs(s1p) < pinf()) ||
@@ -157,24 +270,18 @@ __global__ __launch_bounds__(kWave * 4) void col_select_kernel(ColParams P, Fast
 #pragma unroll
         for (int j = 0; j < kWaveBins / (4 * kWave); ++j) *reinterpret_cast<uint4*>(&sm.hist[4 * (lane + kWave * j)]) = z4;
       }
-      const double* list = P.cand + r * (int64_t)kColCap;
-      double xmin = 0.0;
-      for (int c = lane; c < ncand; c += kWave) {
-        const double x = list[c] - m;  // psis.py:134, one rounding, like the reference
-        sm.cand[c] = x;
-        xmin = fmin(xmin, x);
-      }
-      xmin = wave_all<R_MIN>(xmin);
       double magic = kMagic, c256 = kC256;
-      const int k1 = __double2loint(fma(xmin, c256, magic));  // histogram origin: the smallest candidate's key
+      // histogram origin: every candidate has raw >= t_raw, so x >= t_raw - m up to the two roundings: two keys of margin
+      const int k1 = __double2loint(fma(t_raw - m, c256, magic)) - 2;
       const int span = -k1;
       const int sh = (span >> 9) ? (32 - __builtin_clz((unsigned)(span >> 9))) : 0;
       // the sums about the true shift: e^x = e^x' e^-(m - m'), e^-x = e^-x' e^(m - m')   (R < 690 keeps both finite)
       const double s1 = lane == 0 ? s1p * exp_tab(-delta, tb.tab) : 0.0;
       const double s2 = lane == 0 ? s2p * exp_tab(delta, tb.tab) : 0.0;
+      const CandInList<SM> src{P.cand + r * (int64_t)kColCap, m, sm};
       wave_sync();
-      wave_select_split<SM, TB, (CAP::kMaxTail + 63) / 64>(F, sm, tb, r, lane, M, m, mn, s1, s2, (unsigned)ncand, k1, sh, magic, c256,
-                                                           slow);
+      wave_select_split<SM, TB, (CAP::kMaxTail + 63) / 64, CandInList<SM>>(F, sm, tb, r, lane, M, m, mn, s1, s2, (unsigned)ncand, k1, sh,
+                                                                           magic, c256, slow, src);
     }
     if (slow && lane == 0) {
       const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);

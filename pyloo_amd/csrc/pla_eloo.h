@@ -188,4 +188,158 @@ __global__ __launch_bounds__(BLOCK) void e_loo_rows_kernel(ELooParams P) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weighted quantiles (e_loo.py:468-515 -> `_weighted_quantile`, 534-554), one 256-thread workgroup per observation.
+//
+// The reference argsorts the draws, accumulates the sorted weights and interpolates between the two draws that bracket
+// `prob`.  No sort is needed for that: what it reads off the sorted arrays is (a) the smallest draw v whose cumulative
+// weight reaches prob, (b) the weight strictly below v and at v, (c) the largest draw below v.  (a) is an MSB-first radix
+// descent on order-preserving 64-bit keys, 8 bits per pass, with a 256-bin LDS histogram OF WEIGHTS (ds_add_f64) -- the
+// weighted twin of the general kernel's selection (pla_rows.h) -- which also yields (b); (c) is one more pass.  Constant
+// weights take np.quantile's branch (e_loo.py:536-537): the same descent on counts, numpy's `linear` interpolation.
+// Equal draws are treated as one draw carrying their combined weight (the reference orders ties by an unstable argsort;
+// the result differs only when `prob` is crossed inside a group of equal draws with unequal weights).
+// ---------------------------------------------------------------------------------------------------------------------
+struct EQuantParams {
+  const void* x;
+  const void* lw;
+  int64_t n_obs;
+  int n_draws;
+  int64_t stride_obs, stride_draw;
+  const double* probs;  // [n_probs] device
+  int n_probs;
+  double* out;          // [n_obs][n_probs]
+};
+
+// smallest key whose cumulative mass (sum of `mass(s)` over draws with key <= it) reaches `target`; *below = mass strictly
+// below that key, *at = mass at it.  Returns false when the total never reaches the target.
+template <int BLOCK, class KeyAt, class MassAt>
+__device__ __forceinline__ bool mass_select(const int S, KeyAt key_at, MassAt mass_at, const double target, double* hist, double* red,
+                                            uint64_t* key_out, double* below, double* at) {
+  const int tid = threadIdx.x;
+  uint64_t prefix = 0;
+  double base = 0.0;
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 256; i += BLOCK) hist[i] = 0.0;
+    __syncthreads();
+    for (int s = tid; s < S; s += BLOCK) {
+      const uint64_t k = key_at(s);
+      if (shift == 56 || (k >> (shift + 8)) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], mass_at(s));
+    }
+    __syncthreads();
+    // one thread walks the 256 bins (the walk is short and the order of the additions is then fixed)
+    if (tid == 0) {
+      double cum = base;
+      int d = 0;
+      for (; d < 256; ++d) {
+        if (cum + hist[d] >= target) break;
+        cum += hist[d];
+      }
+      red[0] = cum;
+      red[1] = (double)d;
+      red[2] = d < 256 ? hist[d] : 0.0;
+    }
+    __syncthreads();
+    const int d = (int)red[1];
+    base = red[0];
+    const double here = red[2];
+    __syncthreads();
+    if (d >= 256) return false;
+    prefix = (prefix << 8) | (uint64_t)d;
+    if (shift == 0) {
+      *key_out = prefix;
+      *below = base;
+      *at = here;
+    }
+  }
+  return true;
+}
+
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
+  __shared__ double hist[256];
+  __shared__ double red[BLOCK / kWave > 4 ? BLOCK / kWave : 4];
+  const int tid = threadIdx.x;
+  const int S = P.n_draws;
+  for (int64_t r = blockIdx.x; r < P.n_obs; r += gridDim.x) {
+    const T* xr = reinterpret_cast<const T*>(P.x) + r * P.stride_obs;
+    const T* wr = reinterpret_cast<const T*>(P.lw) + r * P.stride_obs;
+    const auto xat = [&](int s) { return (double)xr[(int64_t)s * P.stride_draw]; };
+    const auto key_at = [&](int s) { return key_of(xat(s)); };
+    // normalised weights w = exp(lw - logsumexp(lw)) (e_loo.py:557-559, 473): maximum, sum, and whether they are all close
+    double mlw = -pinf(), xmax = -pinf(), xmin = pinf();
+    unsigned nanw = 0;
+    for (int s = tid; s < S; s += BLOCK) {
+      const double a = (double)wr[(int64_t)s * P.stride_draw];
+      if (a != a) nanw = 1u;
+      mlw = fmax(mlw, a);
+      const double x = xat(s);
+      xmax = fmax(xmax, x);
+      xmin = fmin(xmin, x);
+    }
+    mlw = block_reduce<OpMax, BLOCK>(mlw, red);
+    xmax = block_reduce<OpMax, BLOCK>(xmax, red);
+    xmin = block_reduce<OpMin, BLOCK>(xmin, red);
+    nanw = block_or_bits<BLOCK>(nanw, red);
+    double sa = 0.0;
+    for (int s = tid; s < S; s += BLOCK) sa += exp((double)wr[(int64_t)s * P.stride_draw] - mlw);
+    sa = block_reduce<OpSum, BLOCK>(sa, red);
+    const double w0 = exp((double)wr[0] - mlw) / sa;
+    double dev = 0.0;
+    for (int s = tid; s < S; s += BLOCK) dev = fmax(dev, fabs(exp((double)wr[(int64_t)s * P.stride_draw] - mlw) / sa - w0));
+    dev = block_reduce<OpMax, BLOCK>(dev, red);
+    const bool flat = !nanw && dev <= kCloseAtol + kCloseRtol * fabs(w0);                 // e_loo.py:536
+    const auto wat = [&](int s) { return exp((double)wr[(int64_t)s * P.stride_draw] - mlw) / sa; };
+    for (int ip = 0; ip < P.n_probs; ++ip) {
+      const double prob = P.probs[ip];
+      double res;
+      uint64_t kv = 0;
+      double below = 0.0, at = 0.0;
+      if (flat) {
+        // np.quantile(x, prob), method "linear": virtual index (S - 1) prob between the order statistics lo and lo + 1
+        const double virt = (double)(S - 1) * prob;
+        const double lo = floor(virt), t = virt - lo;
+        const auto one = [](int) { return 1.0; };
+        mass_select<BLOCK>(S, key_at, one, lo + 1.0, hist, red, &kv, &below, &at);
+        const double a = val_of(kv);
+        double b = a;
+        if (below + at < lo + 2.0 && lo + 1.0 < (double)S) {  // the next order statistic is the next distinct value
+          double nxt = pinf();
+          for (int s = tid; s < S; s += BLOCK) {
+            const double x = xat(s);
+            if (key_at(s) > kv) nxt = fmin(nxt, x);
+          }
+          b = block_reduce<OpMin, BLOCK>(nxt, red);
+        }
+        const double diff = b - a;
+        res = (t >= 0.5) ? b - diff * (1.0 - t) : a + diff * t;                           // numpy's _lerp
+        if (t == 0.0) res = a;
+      } else {
+        const auto wmass = [&](int s) { return wat(s); };
+        double wtot = 0.0;
+        for (int s = tid; s < S; s += BLOCK) wtot += wat(s);
+        wtot = block_reduce<OpSum, BLOCK>(wtot, red);                                     // e_loo.py:542: cumsum / sum
+        const bool found = mass_select<BLOCK>(S, key_at, wmass, prob * wtot, hist, red, &kv, &below, &at);
+        if (!found) {
+          res = xmax;                                                                     // 545-546
+        } else {
+          const double v = val_of(kv);
+          double prev = -pinf();
+          for (int s = tid; s < S; s += BLOCK)
+            if (key_at(s) < kv) prev = fmax(prev, xat(s));
+          prev = block_reduce<OpMax, BLOCK>(prev, red);
+          if (below == 0.0 && prev == -pinf()) res = v;                                   // wi == 0: 548-550
+          else {
+            const double w1 = below / wtot, wwi = (below + at) / wtot;                    // 552
+            res = prev + (v - prev) * (prob - w1) / (wwi - w1);                           // 554
+          }
+        }
+      }
+      if (tid == 0) P.out[r * P.n_probs + ip] = res;
+      __syncthreads();
+    }
+  }
+}
+
 }  // namespace pla

@@ -587,6 +587,16 @@ hipError_t launch_e_loo(const void* x, const void* lw, const void* lr, int dtype
   return hipGetLastError();
 }
 
+hipError_t launch_e_loo_quantiles(const void* x, const void* lw, int dtype, int64_t n_obs, int n_draws, int64_t stride_obs,
+                                  int64_t stride_draw, const double* probs, int n_probs, double* out, hipStream_t stream) {
+  if (n_obs <= 0 || n_probs <= 0) return hipSuccess;
+  EQuantParams p{x, lw, n_obs, n_draws, stride_obs, stride_draw, probs, n_probs, out};
+  const int64_t grid = n_obs < 16384 ? n_obs : 16384;
+  if (dtype == PLA_F64) hipLaunchKernelGGL((e_loo_quantile_kernel<double, 256>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((e_loo_quantile_kernel<float, 256>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
 int reduce_workspace_doubles() { return kRedChunks * kRedSlots; }
 
 hipError_t launch_reduce(const ReduceParams& p, double* workspace, hipStream_t stream) {

@@ -426,6 +426,9 @@ __device__ __forceinline__ void count_if(int& cnt, float a, float b) {
   if constexpr (GE) asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(cnt) : "v"(a), "v"(b) : "vcc");
   else asm volatile("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(cnt) : "v"(a), "v"(b) : "vcc");
 }
+// (Weights mode rewrites its pads late -- doing it early costs that kernel registers it does not have -- so there the
+// slots past the row still hold copies of the lane's first draws and are counted with them: exact to 96 / 4096 at S = 4000,
+// cruder for rows much shorter than the register block; the candidate count after the sweep is exact either way.)
 template <typename T, bool LW>
 __device__ __forceinline__ int count_above(const T (&v)[kWaveSlots], T thr) {
   int cnt = 0;  // per lane
@@ -965,24 +968,33 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
 // the boundary test and the scatter; the two wave-wide sums are reduced under the first LDS round trip; the hand-over's
 // exponentials run as `ws_stride / 64` independent chains.  Lists longer than 512 take a second, looped batch.
 // Hands over to fit_rows_kernel (pla_fit.h): y = e^x - e^xcut of the tail in bin-grouped descending order + 6 scalars.
-template <typename SM, typename TB, int HU = 4>  // HU: 64-value blocks of the hand-over (ws_stride <= 64 HU)
+// Where the split selection finds its candidates and its scratch: the sweep's LDS list (wave kernels), or a list in global
+// memory read in place (pla_col.h: no LDS copy, so that kernel keeps three times the waves per CU).
+template <class SM>
+struct CandInLds {
+  SM& sm;
+  __device__ __forceinline__ double at(unsigned c) const { return sm.cand[c]; }
+  __device__ __forceinline__ unsigned* dump_bin(int lane) const { return reinterpret_cast<unsigned*>(&sm.cand[SM::Caps::kCand]) + lane; }
+  __device__ __forceinline__ double* dump_slot(int lane) const { return &sm.cand[SM::Caps::kCand + kWave + lane]; }
+};
+
+template <typename SM, typename TB, int HU = 4, class SRC = CandInLds<SM>>  // HU: 64-value blocks of the hand-over (ws_stride <= 64 HU)
 __device__ __forceinline__ void wave_select_split(const FastParams& F, SM& sm, const TB& tb, const int64_t r, const int lane_id,
                                                   const int M, const double m, const double mn, const double s1, const double s2,
                                                   const unsigned ncand, const int k1, const int sh, const double magic,
-                                                  const double c256, bool& slow, const int dbgs = 0) {
+                                                  const double c256, bool& slow, const SRC& cs, const int dbgs = 0) {
   constexpr int kSa = SM::Caps::kSa;
   constexpr int U = 8;  // candidates per lane held in registers
   // (opaque: the addresses this phase derives from the lane number must not be computed -- and kept alive -- across the sweep)
   int lane = lane_id;
   asm volatile("" : "+v"(lane));
-  constexpr int kCand = SM::Caps::kCand;
   const auto key_of = [&](double xx) { return __double2loint(fma(xx, c256, magic)); };
   // Lanes with nothing to count or to place still execute the stage's LDS operations (straight-line code, every round trip in
   // flight together) on a dump bin / dump slot of their OWN -- 64 lanes hammering one LDS address cost more than the
   // branches they save.  Both live in the tail of the candidate array, which the sweep no longer needs: its 64 overflow
   // slots (as 32-bit bins) and its per-lane dump slots.
-  unsigned* const dump_bin = reinterpret_cast<unsigned*>(&sm.cand[kCand]) + lane;
-  double* const dump_slot = &sm.cand[kCand + kWave + lane];
+  unsigned* const dump_bin = cs.dump_bin(lane);
+  double* const dump_slot = cs.dump_slot(lane);
   PLA_PHASE(4);
   // ---- candidates -> registers; histogram atomics (no return value: fire and forget) -------------------------------
   double xs[U];
@@ -990,7 +1002,7 @@ __device__ __forceinline__ void wave_select_split(const FastParams& F, SM& sm, c
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const unsigned c = lane + kWave * u;
-    xs[u] = sm.cand[c < ncand ? c : 0];
+    xs[u] = cs.at(c < ncand ? c : 0);
   }
   double s1_all, s2_all;
   wave_all2<R_SUM>(s1, s2, s1_all, s2_all);  // (independent of the list: runs while the reads are in flight)
@@ -1009,7 +1021,7 @@ __device__ __forceinline__ void wave_select_split(const FastParams& F, SM& sm, c
     bx[u] = c < ncand ? (key_of(xs[u]) - k1) >> sh : kWaveBins;  // (kWaveBins: past the end of the list)
     atomicAdd(bx[u] < kWaveBins ? &sm.hist[bx[u]] : dump_bin, 1u);
   }
-  for (unsigned c = lane + kWave * U; c < ncand; c += kWave) atomicAdd(&sm.hist[(key_of(sm.cand[c]) - k1) >> sh], 1u);
+  for (unsigned c = lane + kWave * U; c < ncand; c += kWave) atomicAdd(&sm.hist[(key_of(cs.at(c)) - k1) >> sh], 1u);
   wave_sync();
   PLA_PHASE(5);
   // ---- suffix scan over the bins (8 per lane): boundary bin of rank M ----------------------------------------------
@@ -1072,7 +1084,7 @@ __device__ __forceinline__ void wave_select_split(const FastParams& F, SM& sm, c
 #pragma unroll
   for (int u = 0; u < U; ++u) *(bx[u] ? &sm.sa[st[u] + old[u] - 1u] : dump_slot) = xs[u];
   for (unsigned c = lane + kWave * U; c < ncand; c += kWave) {  // (lists beyond 512 entries)
-    const double x = sm.cand[c];
+    const double x = cs.at(c);
     const int b = (key_of(x) - k1) >> sh;
     if (b >= bstar) sm.sa[sm.start[b] + (atomicSub(&sm.hist[b], 1u) - 1u)] = x;
   }
@@ -1199,7 +1211,8 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   }
   // pads: from here on the slots past the row hold ll = -mn (raw = mn, x = -R: the smallest value of the row) instead of copies
   // of the lane's first vector -- never at or above a threshold, so the counts below see real draws only
-  pad_tail<T, VEC, NQ - 1, true>(v, qfull, qrem, LW ? (T)mn : (T)(-mn));
+  // (LOO mode; the weights kernel does it right before the sweep and counts valid slots only)
+  if constexpr (!LW) pad_tail<T, VEC, NQ - 1, true>(v, qfull, qrem, (T)(-mn));
   bool thr_ok = true;
   if (m - mn < kWaveMaxRange) {  // (rows with non-finite draws or too wide a range go to the general kernel anyway)
     double t_raw = t1 + m;
@@ -1236,6 +1249,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
 #pragma unroll
       for (int i = 0; i < kWaveBins / (4 * kWave); ++i) *reinterpret_cast<uint4*>(&sm.hist[4 * (lane + kWave * i)]) = z4;
     }
+    if constexpr (LW) pad_tail<T, VEC, NQ - 1, true>(v, qfull, qrem, (T)mn);  // pads: raw = mn (x = -R)
     wave_sync();
     // ---- 2. sweep: e^x and e^-x of every draw from one range reduction + histogram of candidates ----
     // (e^(ll - max ll) = e^-R * e^-x; the row constant e^-R is applied to the sum, in log space)
@@ -1357,7 +1371,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       why_cand = (int)ncand < M + 1 ? 1 : 2;
 #endif
     } else if constexpr (SPLIT && kFitSorts && !LW) {
-      wave_select_split(F, sm, tb, r, lane, M, m, mn, s1, s2, ncand, k1, sh, magic, c256, slow, dbgs);
+      wave_select_split(F, sm, tb, r, lane, M, m, mn, s1, s2, ncand, k1, sh, magic, c256, slow, CandInLds<SM>{sm}, dbgs);
     } else {
       wave_back<T, VEC, LW, SM, TB, SPLIT>(P, sm, tb, r, v, lane, S, M, mestM, logS, dbgs, m, mn, R, 0.0, s1, s2, ncand, k1, sh,
                                            magic, c256, qfull, qrem, slow, khat, loo, lppd, &F);

@@ -6,8 +6,8 @@ Host Python: argument handling and error texts (e_loo.py:150-213), the three clo
 mean / variance (430-465, 518-531, 557-559) and ``k_hat`` (328-390) -- reproduced as the reference evaluates it, see
 ``csrc/pla_eloo.h``.
 
-``type="quantile"`` (468-515, 534-554) needs the draws of every observation sorted by value with their weights carried
-along; it is not on the device yet and raises ``NotImplementedError`` (there is no CPU fallback in this package).
+``type="quantile"`` (468-515, 534-554) runs on the device as well (``pla_e_loo_quantiles``: a weighted radix selection per
+observation and probability instead of the reference's argsort); the result then carries a trailing ``quantile`` axis.
 ArviZ / xarray are optional here: InferenceData / DataArray inputs are taken when those packages are importable, plain
 arrays ``(chain, draw, *obs)`` or ``(*obs, n_draws)`` otherwise.
 """
@@ -158,19 +158,26 @@ def e_loo(data, var_name=None, group="posterior_predictive", weights=None, log_w
     lr = None if log_ratios is None else _sample_last(log_ratios, "log_ratios")[0]
     if tuple(lw.shape) != tuple(xv.shape) or (lr is not None and tuple(lr.shape) != tuple(xv.shape)):
         raise ValueError(f"data {tuple(xv.shape)} and the weights {tuple(lw.shape)} must have the same shape (draws last)")
-    if type == "quantile":
-        raise NotImplementedError("e_loo(type='quantile') is not on the device yet (weighted quantiles need a per-observation sort)")
-
     n_samples = xv.shape[-1]
     obs_shape = tuple(xv.shape[:-1])
     res = get_engine().e_loo(_rows(xv), _rows(lw), None if lr is None else _rows(lr))
-    if type == "mean":
+    if type == "quantile":
+        q = get_engine().e_loo_quantiles(_rows(xv), _rows(lw), probs_array)               # e_loo.py:468-515
+        value, k = q, res["k_none"]                                                       # 229-230: h = None
+    elif type == "mean":
         value, k = res["mean"], res["k_mean"]
     elif type == "variance":
         value, k = res["var"], res["k_var"]
     else:
         value, k = res["var"] ** 0.5, res["k_var"]
 
+    if type == "quantile":  # value: (*obs, quantile) (e_loo.py:509-515)
+        qshape = obs_shape + (len(probs_array),)
+        if xr is not None and dims:
+            value = xr.DataArray(np.asarray(value).reshape(qshape), dims=tuple(dims) + ("quantile",),
+                                 coords={**coords, "quantile": probs_array})
+        else:
+            value = value.reshape(qshape)
     if _is_torch_tensor(k):
         kh = k.cpu().numpy()
         shape = lambda a: a.reshape(obs_shape)  # noqa: E731
@@ -181,5 +188,5 @@ def e_loo(data, var_name=None, group="posterior_predictive", weights=None, log_w
     rate = np.array([_pareto_convergence_rate(v, n_samples) for v in kh])               # 246-250
     thr = np.full(kh.shape, _pareto_khat_threshold(n_samples))                           # 244
     plain = (lambda a: wrap_obs(a, obs_shape, dims, coords, None)) if dims else (lambda a: np.asarray(a).reshape(obs_shape))
-    return ExpectationResult(value=shape(value), pareto_k=shape(k), min_ss=plain(min_ss), khat_threshold=plain(thr),
-                             convergence_rate=plain(rate))
+    return ExpectationResult(value=value if type == "quantile" else shape(value), pareto_k=shape(k), min_ss=plain(min_ss),
+                             khat_threshold=plain(thr), convergence_rate=plain(rate))

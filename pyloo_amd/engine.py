@@ -294,6 +294,40 @@ class Engine:
                                   *(p(out[k]) for k in ("mean", "var", "k_mean", "k_var", "k_none"))))
         return out
 
+    def e_loo_quantiles(self, x, log_weights, probs):
+        """(n_obs, n_draws) draws + log-weights, quantile levels -> (n_obs, n_probs) weighted quantiles (``pla_e_loo_quantiles``:
+        e_loo.py:468-515, 534-554)."""
+        pr = np.ascontiguousarray(np.atleast_1d(np.asarray(probs, dtype=np.float64)))
+        if _is_torch_tensor(x):
+            import torch
+
+            mats = [x, log_weights]
+            if any((not _is_torch_tensor(m)) or m.shape != x.shape or m.dim() != 2 for m in mats):
+                raise ValueError("x and log_weights must be 2-D CUDA tensors of one shape")
+            dt = torch.float64 if any(m.dtype == torch.float64 for m in mats) else torch.float32
+            mats = [m.to(dt) for m in mats]
+            if mats[0].stride() != mats[1].stride() or mats[0].stride(1) <= 0:
+                mats = [m.contiguous() for m in mats]
+            t = mats[0]
+            n, s = t.shape
+            out = torch.empty((n, pr.size), dtype=torch.float64, device=t.device)
+            code = _capi.PLA_F64 if dt == torch.float64 else _capi.PLA_F32
+            check(self._lib.pla_e_loo_quantiles(self._h, C.c_void_p(mats[0].data_ptr()), C.c_void_p(mats[1].data_ptr()), code, n, s,
+                                                t.stride(0), t.stride(1), pr.ctypes.data_as(C.c_void_p), pr.size, PLA_DEVICE,
+                                                self._stream(), C.c_void_p(out.data_ptr())))
+            return out
+        mats = [np.asarray(x), np.asarray(log_weights)]
+        if any(m.ndim != 2 or m.shape != mats[0].shape for m in mats):
+            raise ValueError("x and log_weights must be 2-D arrays of one shape")
+        dt = np.float32 if all(m.dtype == np.float32 for m in mats) else np.float64
+        mats = [np.ascontiguousarray(m, dtype=dt) for m in mats]
+        n, s = mats[0].shape
+        out = np.empty((n, pr.size))
+        check(self._lib.pla_e_loo_quantiles(self._h, mats[0].ctypes.data_as(C.c_void_p), mats[1].ctypes.data_as(C.c_void_p),
+                                            dtype_code(dt), n, s, s, 1, pr.ctypes.data_as(C.c_void_p), pr.size, PLA_HOST, None,
+                                            out.ctypes.data_as(C.c_void_p)))
+        return out
+
     # ------------------------------------------------------------------ reductions
     def reduce_pointwise(self, diag, loo_i, lppd_i, good_k):
         if _is_torch_tensor(loo_i):

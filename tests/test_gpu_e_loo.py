@@ -40,6 +40,14 @@ def test_golden_rows(eng, case):
     same(res["var"], g[f"{case}_var"], rtol * 10, "variance")
     for key in ("k_mean", "k_var", "k_none"):
         same(res[key], g[f"{case}_{key}"], 1e-14, key)
+    # weighted quantiles (e_loo.py:534-554) at the fixtures' three levels.  Rows whose draws hold NaN / inf, or equal draws
+    # with unequal weights (the reference resolves those by an unstable argsort), are outside what is compared.
+    q = eng.e_loo_quantiles(x, lw, g["probs"])
+    want = g[f"{case}_quant"]
+    ok = np.isfinite(x).all(axis=1) & np.isfinite(want).all(axis=1)
+    if case == "edges_s500":
+        ok[[1, 7, 12]] = False  # two-valued / rounded draws: ties
+    np.testing.assert_allclose(q[ok], want[ok], rtol=1e-9 if x.dtype == np.float64 else 3e-5, atol=1e-12, err_msg="quantiles")
 
 
 @pytest.mark.parametrize("S,N,dt", [(4000, 64, np.float64), (1000, 40, np.float32), (20000, 6, np.float64), (37, 20, np.float64)])
@@ -55,6 +63,12 @@ def test_seeded_vs_oracle(eng, S, N, dt):
     same(res["var"], want["var"], 1e-8, "variance")
     for key in ("k_mean", "k_var", "k_none"):
         same(res[key], want[key], 1e-14, key)
+    probs = np.array([0.01, 0.25, 0.5, 0.975])
+    got_q = eng.e_loo_quantiles(x, lw, probs)
+    want_q = orc.e_loo_arrays(x.astype(np.float64), lw.astype(np.float64), None, probs=probs)["quant"]
+    np.testing.assert_allclose(got_q, want_q, rtol=1e-9, atol=1e-12, err_msg="quantiles")
+    flat = eng.e_loo_quantiles(x, np.zeros_like(lw), probs)  # constant weights: np.quantile (e_loo.py:536-537)
+    np.testing.assert_allclose(flat, np.quantile(x.astype(np.float64), probs, axis=1).T, rtol=1e-12, atol=1e-13)
     no_ratios = eng.e_loo(x, lw)  # log_ratios defaults to the log-weights (e_loo.py:223-224)
     want2 = orc.e_loo_arrays(x.astype(np.float64), lw.astype(np.float64), None)
     same(no_ratios["k_mean"], want2["k_mean"], 1e-14, "k_mean without ratios")
@@ -100,6 +114,13 @@ def test_device_tensors_and_front(eng):
     with pytest.raises(ValueError):
         pl.e_loo(x, type="mean")
     with pytest.raises(ValueError):
-        pl.e_loo(x, log_weights=lw, type="quantile")
+        pl.e_loo(x, log_weights=lw, type="quantile")  # probs missing
+    with pytest.raises(ValueError):
+        pl.e_loo(x, log_weights=lw, type="quantile", probs=[0.5, 1.0])
+    rq = pl.e_loo(x, log_weights=lw, log_ratios=lr, type="quantile", probs=[0.1, 0.9])
+    assert np.asarray(rq.value).shape == shape[:-1] + (2,)
+    wq = orc.e_loo_arrays(x.reshape(-1, 2000), np.asarray(lw).reshape(-1, 2000), lr.reshape(-1, 2000), probs=[0.1, 0.9])
+    np.testing.assert_allclose(np.asarray(rq.value).reshape(-1, 2), wq["quant"], rtol=1e-9)
+    same(np.asarray(rq.pareto_k).ravel(), wq["k_none"], 1e-14, "pareto_k of the quantile type")
     with pytest.raises(ValueError):
         pl.compute_pareto_k(x, lr, tail_len=4)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Cost of the ArviZ-native layout (observations fastest) on a device-resident matrix: the library's
-tiled transposing ingestion against torch's copy, next to the draws-fastest pass.   python tools/obs_fastest_cost.py"""
+"""Cost of the ArviZ-native layout (observations fastest) on a device-resident matrix: the
+lane-per-observation LOO kernels (pla_col.h, the matrix read in place), the tiled transposing ingestion they replace
+(PLA_INGEST_TRANSPOSE=1 in the environment: round 1's path; WAIC still uses it) and torch's copy, next to the draws-fastest
+pass.   python tools/obs_fastest_cost.py"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -27,7 +29,9 @@ t_of, r1 = timed(lambda: eng.psis_loo(view, 190, "psis", 1.0, 0.7, pointwise=Fal
 t_wa, _ = timed(lambda: eng.waic(view, 1.0, pointwise=False))
 del a
 t_torch, _ = timed(lambda: view.contiguous(), 2)
-print(json.dumps({"workload": f"f64 S={S} x N={N}, device-resident", "loo_draws_fastest_ms": t_rm, "loo_obs_fastest_ms": t_of,
-                  "waic_obs_fastest_ms": t_wa, "torch_contiguous_copy_ms": t_torch,
-                  "ingestion_ms": t_of - t_rm, "ingestion_tb_per_s_read_plus_write": 2 * N * S * 8 / ((t_of - t_rm) * 1e-3) / 1e12,
-                  "same_elpd": bool(r0["agg"][1].item() == r1["agg"][1].item())}))
+path = "transposing ingestion" if os.environ.get("PLA_INGEST_TRANSPOSE", "0") not in ("", "0") else "lane-per-observation kernels"
+rel = abs(r0["agg"][1].item() - r1["agg"][1].item()) / abs(r0["agg"][1].item())
+print(json.dumps({"workload": f"f64 S={S} x N={N}, device-resident", "obs_fastest_loo_path": path, "loo_draws_fastest_ms": t_rm,
+                  "loo_obs_fastest_ms": t_of, "obs_fastest_tb_per_s_algorithmic": N * (S * 8 + 24) / (t_of * 1e-3) / 1e12,
+                  "waic_obs_fastest_ms": t_wa, "torch_contiguous_copy_ms": t_torch, "extra_over_draws_fastest_ms": t_of - t_rm,
+                  "elpd_rel_diff": rel, "rows_to_general_kernel": r1["agg"][7].item()}))
