@@ -766,7 +766,12 @@ static int waic_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_src, 
       if (!dv) dv = eng->d_pw;
       if (!dw) dw = eng->d_pw + n_obs;
     }
-    if (obs_fastest_device(mem_space, row_index, n_src, n_draws, stride_obs, stride_draw)) {
+    static const bool force_transpose = getenv("PLA_INGEST_TRANSPOSE") && atoi(getenv("PLA_INGEST_TRANSPOSE")) != 0;
+    if (obs_fastest_device(mem_space, row_index, n_src, n_draws, stride_obs, stride_draw) && !force_transpose) {
+      // observations-fastest matrix, read in place: one lane per observation (pla_waic.h)
+      TimedLaunch t(eng, s);
+      PLA_HIP(pla::launch_waic_col(ll, dtype, n_obs, (int)n_draws, stride_draw, scale_value, dl, dv, dw, eng->counters + 1, s));
+    } else if (obs_fastest_device(mem_space, row_index, n_src, n_draws, stride_obs, stride_draw)) {
       const int64_t rows_per_chunk = staged_chunk_rows(mem_space, true, n_obs, n_draws, esz);
       rc = grow(&eng->d_in, &eng->d_in_bytes, (size_t)rows_per_chunk * (size_t)n_draws * esz);
       if (rc) return rc;

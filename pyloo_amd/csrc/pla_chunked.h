@@ -227,15 +227,17 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
 template <typename T, int VEC, class CAP, bool SPLIT = false>
 __global__ __launch_bounds__(kWave * CAP::kWaves, 1) void wave_loo_chunked_kernel(RowsParams P, FastParams F) {
   using SM = WaveSmemT<CAP>;
-  using TB = WaveTablesT<CAP>;
+  using TB = std::conditional_t<SPLIT, WaveTabOnly, WaveTablesT<CAP>>;
   constexpr int kWavesPerBlock = CAP::kWaves;
   __shared__ __attribute__((aligned(16))) SM scratch[kWavesPerBlock];
   __shared__ __attribute__((aligned(16))) TB tb;
   const int tid = threadIdx.x;
   for (int j = tid; j < kTabN; j += kWave * kWavesPerBlock) exp_table_entry(tb.tab, j);
-  for (int j = tid; j < kLogTabN; j += kWave * kWavesPerBlock) log_table_entry(tb.lt, j);
-  for (int j = tid; j < P.tail_count; j += kWave * kWavesPerBlock) tb.l1[j] = F.l1_table[j];
-  if (tid < kWave) tb.bg[tid] = F.b_grid[tid];
+  if constexpr (!SPLIT) {
+    for (int j = tid; j < kLogTabN; j += kWave * kWavesPerBlock) log_table_entry(tb.lt, j);
+    for (int j = tid; j < P.tail_count; j += kWave * kWavesPerBlock) tb.l1[j] = F.l1_table[j];
+    if (tid < kWave) tb.bg[tid] = F.b_grid[tid];
+  }
   __syncthreads();
   const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
   SM& sm = scratch[wv];

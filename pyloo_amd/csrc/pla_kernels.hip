@@ -208,7 +208,7 @@ static bool wave_threshold_params(int S, int vec, int M, int* gsz_out, int* kq_o
 #define PLA_CAND_MULT 2.2
 #endif
   const double target = PLA_CAND_MULT * (M + 1);
-  if (target > 0.62 * cand_cap || target >= 0.5 * S) return false;
+  if (target > 0.75 * cand_cap || target >= 0.5 * S) return false;  // (the threshold is verified by an exact count before the sweep)
   const double F = 1.0 - target / S;
   const int S0 = S < kWave * kWaveSlots ? S : kWave * kWaveSlots;
   const int qfull = S0 / vec / kWave;  // vectors that are real draws in every lane
@@ -594,6 +594,16 @@ hipError_t launch_e_loo_quantiles(const void* x, const void* lw, int dtype, int6
   const int64_t grid = n_obs < 16384 ? n_obs : 16384;
   if (dtype == PLA_F64) hipLaunchKernelGGL((e_loo_quantile_kernel<double, 256>), dim3((unsigned)grid), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL((e_loo_quantile_kernel<float, 256>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_waic_col(const void* in, int dtype, int64_t n_obs, int n_draws, int64_t ld, double scale_value, double* lppd_i,
+                           double* var_i, double* waic_i, unsigned long long* replaced, hipStream_t stream) {
+  if (n_obs <= 0) return hipSuccess;
+  WaicParams p{in, n_obs, n_draws, 1, ld, scale_value, lppd_i, var_i, waic_i, replaced, nullptr};
+  const unsigned grid = (unsigned)((n_obs + 255) / 256);
+  if (dtype == PLA_F64) hipLaunchKernelGGL(waic_col_kernel<double>, dim3(grid), dim3(256), 0, stream, p, ld);
+  else hipLaunchKernelGGL(waic_col_kernel<float>, dim3(grid), dim3(256), 0, stream, p, ld);
   return hipGetLastError();
 }
 

@@ -181,4 +181,88 @@ __global__ __launch_bounds__(BLOCK) void waic_rows_kernel(WaicParams P) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Observations-fastest matrices (ArviZ's layout behind pyloo's stacked view, waic.py:104-107): ONE LANE PER OBSERVATION,
+// like pla_col.h -- a wave reads draw s of 64 neighbouring observations as one contiguous piece of the matrix and every lane
+// streams down its own observation, in one pass:
+//   * log-sum-exp with a running maximum: a draw above it rescales the sum (a second exponential, taken by the wave only
+//     when one of its lanes meets a new maximum -- ~log S times per lane);
+//   * the variance by batches of U draws: two-pass inside the batch (its draws sit in registers), merged into the running
+//     (n, mean, M2) with the pairwise update of Chan, Golub & LeVeque -- as accurate as np.var's two passes over the row.
+// No transposing pass through HBM (19.7 ms for C3 in round 1): the matrix is read once.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void waic_col_kernel(WaicParams P, int64_t ld) {
+  __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];
+  __shared__ __attribute__((aligned(16))) double lt[2 * kLogTabN];
+  for (int j = threadIdx.x; j < kTabN; j += 256) exp_table_entry(tab, j);
+  for (int j = threadIdx.x; j < kLogTabN; j += 256) log_table_entry(lt, j);
+  __syncthreads();
+  const int S = P.n_draws;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < P.n_obs;
+  const T* col = reinterpret_cast<const T*>(P.in) + (live ? i : P.n_obs - 1);
+  constexpr int U = 8;
+  unsigned nrep = 0;
+  double m = -pinf(), se = 0.0;      // running maximum, sum of exp(x - m)
+  double mean = 0.0, m2 = 0.0;       // Chan: mean and sum of squared deviations of the draws seen so far
+  const auto batch = [&](const double (&x)[U], const int n_before, const int nb) {
+    // ---- log-sum-exp ----
+    double bm = x[0];
+#pragma unroll
+    for (int u = 1; u < U; ++u) bm = (u < nb) ? fmax(bm, x[u]) : bm;
+    if (__ballot(bm > m) != 0ull) {  // some lane has a new maximum: rescale what it has summed so far
+      const double mnew = fmax(m, bm);
+      se *= exp_tab(fmax(m - mnew, -700.0), tab);  // (exp(-inf) on the first batch: se is 0 anyway)
+      m = mnew;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (u < nb) se += exp_tab(fmax(x[u] - m, -700.0), tab);
+    // ---- variance ----
+    double sum = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) sum += (u < nb) ? x[u] : 0.0;
+    const double mb = sum / (double)nb;
+    double qb = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double d = x[u] - mb;
+      qb = (u < nb) ? fma(d, d, qb) : qb;
+    }
+    const double tot = (double)(n_before + nb);
+    const double delta = mb - mean;
+    m2 += qb + delta * delta * ((double)n_before * (double)nb / tot);
+    mean += delta * ((double)nb / tot);
+  };
+  int s = 0;
+#pragma unroll 1
+  for (; s < S; s += U) {
+    const int nb = S - s < U ? S - s : U;  // (wave-uniform)
+    T v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(col + (int64_t)(s + (u < nb ? u : 0)) * ld);
+    double x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      unsigned rep = 0;
+      x[u] = (double)waic_sanitize(v[u], rep);  // waic.py:112-135
+      nrep += (u < nb && live) ? rep : 0u;
+    }
+    batch(x, s, nb);
+  }
+  if (live) {
+    const double var = m2 / (double)S;
+    const double lppd = (log_tab(se, lt) + m) - log((double)S);  // utils.py:352-357
+    if (P.lppd_i) P.lppd_i[i] = lppd;
+    if (P.var_i) P.var_i[i] = var;
+    if (P.waic_i) P.waic_i[i] = P.scale_value * (lppd - var);
+  }
+  if (P.replaced) {
+    __shared__ double red[4];
+    const double tot = block_reduce<OpSum, 256>((double)nrep, red);
+    if (threadIdx.x == 0 && tot > 0.0) atomicAdd(P.replaced, (unsigned long long)tot);
+  }
+}
+
 }  // namespace pla

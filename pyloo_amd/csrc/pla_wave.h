@@ -92,11 +92,15 @@ struct CapsBig {                                    // long rows in chunks / sma
   static constexpr int kMaxTail = 512;
   static constexpr int kWaves = 2;
 };
-struct CapsMid {                                    // chunked rows with M <= 448 (S = 20 000, reff = 1): 6 waves per CU
-  static constexpr int kCand = 1536;
-  static constexpr int kSa = 640;
+struct CapsMid {                                    // chunked rows with M <= 448 (S = 20 000, reff = 1: C5): 8 waves per CU in the
+  static constexpr int kCand = 1280;                // split pass, whose selection kernel keeps the exponential table only (the
+  static constexpr int kSa = 512;                   // fused fallback, with its three more tables, runs one workgroup per CU)
   static constexpr int kMaxTail = 448;
-  static constexpr int kWaves = 3;
+  static constexpr int kWaves = 4;
+};
+// read-only tables of a kernel that only selects (split pass): the fit's tables stay with the fit kernel
+struct WaveTabOnly {
+  double tab[2 * kTabN];
 };
 struct CapsMid4 {                                   // M <= 320 (S up to ~11 000 at reff = 1, or reff >= 0.35 at S = 4000): 8 waves per CU
   static constexpr int kCand = 1088;

@@ -509,6 +509,35 @@ def test_device_path_is_graph_capturable(eng):
     for key in ("diag", "loo_i", "lppd_i", "agg"):
         assert torch.equal(out[key], fresh[key]), key
     assert not torch.equal(out["loo_i"], warm["loo_i"])
+    # frozen workspace (include/pyloo_amd.h, "HIP graphs"): a call that would have to reallocate fails instead of pulling the
+    # buffers from under a captured graph.  On an engine of its own: the shared one has been sized by earlier tests.
+    from pyloo_amd._capi import EngineError
+    from pyloo_amd.engine import Engine
+
+    own = Engine(0)
+    try:
+        small = own.psis_loo(t, 190, "psis", 1.0, 0.7)
+        torch.cuda.synchronize()
+        own.set_frozen(True)
+        bigger = torch.empty((4 * N, S), dtype=torch.float64, device="cuda")
+        eng.fill_synthetic(bigger, seed=13)
+        with pytest.raises(EngineError) as err:
+            own.psis_loo(bigger, 190, "psis", 1.0, 0.7)
+        assert err.value.code == -6
+        with pytest.raises(EngineError):
+            own.psis_loo(t, 150, "psis", 1.0, 0.7)            # a tail count without a table yet: refused as well
+        again = own.psis_loo(t, 190, "psis", 1.0, 0.7)        # what fits still runs
+        torch.cuda.synchronize()
+        assert torch.equal(again["loo_i"], small["loo_i"]) and torch.equal(again["loo_i"], fresh["loo_i"])
+        own.set_frozen(False)
+        own.psis_loo(bigger, 190, "psis", 1.0, 0.7)
+        torch.cuda.synchronize()
+    finally:
+        own.close()
+    other = eng.psis_loo(t, 150, "psis", 1.0, 0.7)          # eager, another M: a second table
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out["loo_i"], fresh["loo_i"]) and not torch.equal(other["loo_i"], fresh["loo_i"])
 
 
 def test_loo_i_front(eng):
@@ -554,9 +583,9 @@ def test_observation_fastest_device_layout(eng):
 @pytest.mark.parametrize("N,S,dt", [(500, 4000, np.float64), (130, 1000, np.float32), (67, 258, np.float64), (2, 4096, np.float64),
                                     (1000, 8000, np.float32)])
 def test_observation_fastest_ingestion(eng, N, S, dt):
-    """Observations-fastest device matrices: the WAIC pass (transposing ingestion, 64 x 16 tiles: ragged tile edges, both
-    dtypes) gives the bits of the draws-fastest copy; the LOO pass reads such a matrix in place with one lane per observation
-    (pla_col.h) where its shape allows, and then agrees to rounding (another order of summation), else bitwise as well."""
+    """Observations-fastest device matrices are read in place with one lane per observation (LOO: pla_col.h where the shape
+    allows, else the transposing ingestion, bitwise; WAIC: waic_col_kernel) and agree with the draws-fastest copy to rounding
+    (another order of summation).  Ragged workgroups, both dtypes."""
     import torch
 
     rng = np.random.default_rng(N + S)
@@ -574,9 +603,9 @@ def test_observation_fastest_ingestion(eng, N, S, dt):
         else:
             np.testing.assert_array_equal(a[key].cpu().numpy(), b[key].cpu().numpy(), err_msg=key)
     assert a["agg"][7].item() == 0
-    wa, wb = eng.waic(view, 1.0), eng.waic(rowmajor, 1.0)
+    wa, wb = eng.waic(view, 1.0), eng.waic(rowmajor, 1.0)  # (one lane per observation as well: pla_waic.h, waic_col_kernel)
     for key in ("lppd_i", "var_i", "waic_i", "agg"):
-        np.testing.assert_array_equal(wa[key].cpu().numpy(), wb[key].cpu().numpy(), err_msg=key)
+        np.testing.assert_allclose(wa[key].cpu().numpy(), wb[key].cpu().numpy(), rtol=1e-11, atol=1e-12, err_msg=key)
     sub = eng.psis_loo(view, M, "psis", 1.0, 0.7, rows=np.array([N - 1, 0]))   # (row selection on such a view: copied first)
     np.testing.assert_array_equal(sub["loo_i"].cpu().numpy(), b["loo_i"].cpu().numpy()[[N - 1, 0]])
 

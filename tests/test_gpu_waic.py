@@ -88,3 +88,30 @@ def test_front_and_full_size(eng):
     loo = eng.psis_loo(t, 190, "psis", 1.0, 0.7)
     w = eng.waic(t, 1.0)
     np.testing.assert_allclose(w["lppd_i"].cpu().numpy(), loo["lppd_i"].cpu().numpy(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("case", [c[0] for c in cases.CASES])
+def test_golden_inputs_observation_fastest(eng, case):
+    """The same golden matrices (NaN, +-inf, constant rows, 1e10 extremes) as (S, N) device buffers viewed as (N, S): the
+    lane-per-observation WAIC kernel (waic_col_kernel) -- running maximum, batched variance, replacements counted."""
+    import torch
+
+    ll = load_golden(case)["ll"]
+    want = orc.waic_arrays(ll.astype(np.float64), 1)
+    view = torch.from_numpy(np.ascontiguousarray(ll.T)).cuda().T
+    assert view.stride(0) == 1 or ll.shape[0] == 1
+    res = {k: v.cpu().numpy() for k, v in eng.waic(view, 1.0).items()}
+    check(res, want, ll.shape[0])
+    assert int(res["agg"][7]) == int(np.sum(~np.isfinite(ll)))
+
+
+def test_observation_fastest_odd_shapes(eng):
+    import torch
+
+    rng = np.random.default_rng(77)
+    for n, s, dt in ((257, 4001, np.float64), (1000, 13, np.float32), (3, 20000, np.float64)):
+        ll = (-0.7 * rng.exponential(size=(n, s)) - 1.0).astype(dt)
+        want = orc.waic_arrays(ll.astype(np.float64), -2)
+        view = torch.from_numpy(np.ascontiguousarray(ll.T)).cuda().T
+        res = {k: v.cpu().numpy() for k, v in eng.waic(view, -2.0).items()}
+        check(res, want, n)

@@ -25,7 +25,7 @@ KERNELS = {
     "wave_loo_chunked_kernelIfLi4ENS_7CapsMidELb1": 81920,    # C5: S = 20 000 f32, M = 425
     "fit_rows_kernelILi7ELi4ELi2": 81920,                     # its fit half (448-value tails, 64-point grid)
     "wave_loo_chunked_kernelIdLi2ENS_8CapsMid4ELb0": 81920,   # fused fallbacks (no workspace / M > 448)
-    "wave_loo_chunked_kernelIfLi4ENS_7CapsMidELb0": 81920,
+    "wave_loo_chunked_kernelIfLi4ENS_7CapsMidELb0": 163840,   # (this fallback carries the fit's tables too: one workgroup per CU)
     "waic_wave_kernelIdLi2": 81920,
     "is_wave_kernelIdLi2ELb0": 81920,
     "is_wave_kernelIdLi2ELb1": 81920,
