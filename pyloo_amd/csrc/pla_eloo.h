@@ -55,9 +55,38 @@ __device__ __forceinline__ double tail_piece(int n_tail, double n_valid, double 
 // Python's max(a, b): a unless b > a
 __device__ __forceinline__ double py_max(double a, double b) { return (b > a) ? b : a; }
 
+// K reductions for the price of one barrier pair: op[k] = 0 sum, 1 max, 2 min; every thread ends with all K results
+template <int K, int BLOCK>
+__device__ __forceinline__ void block_reduce_k(double (&v)[K], const int (&op)[K], double* lds) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (op[k] == 0) v[k] = wave_reduce<OpSum>(v[k]);
+    else if (op[k] == 1) v[k] = wave_reduce<OpMax>(v[k]);
+    else v[k] = wave_reduce<OpMin>(v[k]);
+  }
+  constexpr int NW = BLOCK / kWave;
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) lds[w * K + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double r = lds[k];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) {
+      const double o = lds[i * K + k];
+      r = op[k] == 0 ? r + o : (op[k] == 1 ? fmax(r, o) : fmin(r, o));
+    }
+    v[k] = r;
+  }
+}
+
 template <typename T, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void e_loo_rows_kernel(ELooParams P) {
-  __shared__ double red[BLOCK / kWave];
+  __shared__ double red[(BLOCK / kWave) * 12];
   const int tid = threadIdx.x;
   const int S = P.n_draws;
   const int n_tail = S < P.tail_len ? S : P.tail_len;
@@ -88,12 +117,12 @@ __global__ __launch_bounds__(BLOCK) void e_loo_rows_kernel(ELooParams P) {
       xdev = fmax(xdev, fabs(x - x0));
       qdev = fmax(qdev, fabs(q - q0));
     }
-    mlw = block_reduce<OpMax, BLOCK>(mlw, red);
-    mlr = block_reduce<OpMax, BLOCK>(mlr, red);
-    xmn = block_reduce<OpMin, BLOCK>(xmn, red); xmx = block_reduce<OpMax, BLOCK>(xmx, red);
-    qmn = block_reduce<OpMin, BLOCK>(qmn, red); qmx = block_reduce<OpMax, BLOCK>(qmx, red);
-    xdev = block_reduce<OpMax, BLOCK>(xdev, red);
-    qdev = block_reduce<OpMax, BLOCK>(qdev, red);
+    {
+      double a[8] = {mlw, mlr, xmn, xmx, qmn, qmx, xdev, qdev};
+      const int op[8] = {1, 1, 2, 1, 2, 1, 1, 1};
+      block_reduce_k<8, BLOCK>(a, op, red);
+      mlw = a[0]; mlr = a[1]; xmn = a[2]; xmx = a[3]; qmn = a[4]; qmx = a[5]; xdev = a[6]; qdev = a[7];
+    }
     flags = block_or_bits<BLOCK>(flags, red);
     if (flags & 1u) mlw = qnan();  // np.max propagates NaN (utils.py:346, e_loo.py:350)
     if (flags & 2u) mlr = qnan();
@@ -122,16 +151,13 @@ __global__ __launch_bounds__(BLOCK) void e_loo_rows_kernel(ELooParams P) {
       if (x != xmn && x != xmx) other_x += 1.0;
       if (q != qmn && q != qmx) other_q += 1.0;
     }
-    sa = block_reduce<OpSum, BLOCK>(sa, red);
-    sb = block_reduce<OpSum, BLOCK>(sb, red);
-    sc = block_reduce<OpSum, BLOCK>(sc, red);
-    sd = block_reduce<OpSum, BLOCK>(sd, red);
-    n_valid = block_reduce<OpSum, BLOCK>(n_valid, red);
-    n_close_r = block_reduce<OpSum, BLOCK>(n_close_r, red);
-    other_x = block_reduce<OpSum, BLOCK>(other_x, red);
-    other_q = block_reduce<OpSum, BLOCK>(other_q, red);
-    h1mn = block_reduce<OpMin, BLOCK>(h1mn, red); h1mx = block_reduce<OpMax, BLOCK>(h1mx, red);
-    h2mn = block_reduce<OpMin, BLOCK>(h2mn, red); h2mx = block_reduce<OpMax, BLOCK>(h2mx, red);
+    {
+      double a[12] = {sa, sb, sc, sd, n_valid, n_close_r, other_x, other_q, h1mn, h1mx, h2mn, h2mx};
+      const int op[12] = {0, 0, 0, 0, 0, 0, 0, 0, 2, 1, 2, 1};
+      block_reduce_k<12, BLOCK>(a, op, red);
+      sa = a[0]; sb = a[1]; sc = a[2]; sd = a[3]; n_valid = a[4]; n_close_r = a[5]; other_x = a[6]; other_q = a[7];
+      h1mn = a[8]; h1mx = a[9]; h2mn = a[10]; h2mx = a[11];
+    }
     if (mlr == pinf()) n_close_r = n_valid;  // (a +inf ratio: the valid r are all exp(-inf) = 0, equal to their first)
     // ---- pass 3: how many values of h r lie within the allclose tolerance of each extreme ------------------------
     double c1l = 0.0, c1r = 0.0, c2l = 0.0, c2r = 0.0;
@@ -151,8 +177,12 @@ __global__ __launch_bounds__(BLOCK) void e_loo_rows_kernel(ELooParams P) {
         }
       }
     }
-    c1l = block_reduce<OpSum, BLOCK>(c1l, red); c1r = block_reduce<OpSum, BLOCK>(c1r, red);
-    c2l = block_reduce<OpSum, BLOCK>(c2l, red); c2r = block_reduce<OpSum, BLOCK>(c2r, red);
+    {
+      double a[4] = {c1l, c1r, c2l, c2r};
+      const int op[4] = {0, 0, 0, 0};
+      block_reduce_k<4, BLOCK>(a, op, red);
+      c1l = a[0]; c1r = a[1]; c2l = a[2]; c2r = a[3];
+    }
     if (tid == 0) {
       // ---- expectations ----
       const double mean = sb / sa, msq = sc / sa, wss = sd / (sa * sa);

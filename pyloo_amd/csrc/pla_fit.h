@@ -39,6 +39,9 @@ constexpr int kFitCoefStride = 6;  // (VALU grid pass) doubles per quad in LDS, 
 #ifndef PLA_FIT_PIN
 #define PLA_FIT_PIN 1  // pairs of tail elements of the smoothing pass the scheduler may interleave
 #endif
+#ifndef PLA_FIT_MIN_WAVES
+#define PLA_FIT_MIN_WAVES 2  // waves per SIMD the fit kernel is compiled for
+#endif
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 struct FitParams {
@@ -79,7 +82,7 @@ __device__ __forceinline__ int row_all_add(int v) {
 
 // NQ: 64-value blocks of the tail (4 NQ values per lane); G: grid points per lane (16 G >= m_est); W: waves per workgroup
 template <int NQ, int G = 3, int W = kFitWaves>
-__global__ __launch_bounds__(kWave * W, 2) void fit_rows_kernel(FitParams Q) {
+__global__ __launch_bounds__(kWave * W, PLA_FIT_MIN_WAVES) void fit_rows_kernel(FitParams Q) {
   constexpr int kFitWaves = W;  // (shadows the default: everything below is per instantiation)
   __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];
   __shared__ __attribute__((aligned(16))) double lt[2 * kLogTabN];

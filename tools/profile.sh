@@ -13,6 +13,8 @@ OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="$ROOT/bench.py --obs $OBS --steps $STEPS --warmup 2 --no-cpu"
+# CONFIG=C5 (etc.): a BASELINE preset instead of --obs (its shapes come from bench.py)
+if [ -n "$CONFIG" ]; then ARGS="$ROOT/bench.py --config $CONFIG --steps $STEPS --warmup 2 --no-cpu"; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || tail -5 $OUT/trace.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/fetch.log 2>&1 || tail -5 $OUT/fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/write.log 2>&1 || tail -5 $OUT/write.log
@@ -37,7 +39,7 @@ trace = collections.defaultdict(list)
 for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         trace[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
-lines = ["# rocprofv3 summary ($TAG): bench.py --obs %d --steps $STEPS --warmup 2" % obs, "",
+lines = ["# rocprofv3 summary ($TAG): bench.py ${CONFIG:+--config $CONFIG }--obs %d --steps $STEPS --warmup 2" % obs, "",
          "| kernel | calls | avg ms (all launches) | avg ms (last $STEPS = timed) | total ms | % |", "|---|---|---|---|---|---|"]
 summary = {"obs": obs, "kernels": {}}
 for name, r in sorted(stats.items(), key=lambda kv: -float(kv[1]["TotalDurationNs"])):
