@@ -24,13 +24,12 @@ namespace pla {
 
 constexpr int kChunkDraws = kWave * kWaveSlots;  // 4096
 
-template <typename T, int VEC, typename SM, typename TB, bool SPLIT = false>
+template <typename T, int VEC, typename SM, typename TB, bool SPLIT = false, bool LW = false>
 __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const FastParams& F, SM& sm, const TB& tb,
                                                     const int64_t r, T (&v)[kWaveSlots], const T* row, const T* rp_next) {
   constexpr int EPT = kWaveSlots;
   constexpr int NQ = EPT / VEC;
   constexpr int kCand = SM::Caps::kCand;
-  constexpr bool LW = false;
   // (opaque to the optimiser: otherwise every lane-derived mask of the later phases is hoisted out of the ROW loop into
   // scalar registers, which that loop does not have -- they were being spilled to vector lanes)
   int lane = wave_lane();
@@ -78,7 +77,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
     // ---- pad fix-up (copies of the lane's first vector), max / min of the chunk --------------------
     pad_tail<T, VEC, NQ - 1, false>(v, qfull, qrem, (T)0);
     double mx, mn, gs;
-    row_stats<T, VEC, false>(v, gsz, sbits, mx, mn, gs);  // (gs: the threshold sample, used for chunk 0 only)
+    row_stats<T, VEC, LW>(v, gsz, sbits, mx, mn, gs);  // (gs: the threshold sample, used for chunk 0 only)
     double mc, nmnc;
     wave_all2<R_MAX>(mx, -mn, mc, nmnc);  // min = -max(-.)
     const double mnc = -nmnc;
@@ -86,7 +85,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
     mn_run = fmin(mn_run, mnc);
     if (ch == 0) {
       // (a row that is its own last chunk has pads: make them the row minimum before anything is counted)
-      if (last) pad_tail<T, VEC, NQ - 1, true>(v, qfull, qrem, (T)(-mn_run));
+      if (last) pad_tail<T, VEC, NQ - 1, true>(v, qfull, qrem, LW ? (T)mn_run : (T)(-mn_run));
       // speculative threshold from the first chunk's group maxima (see pla_wave.h); shift = its maximum
       mp = mc;
       double lo = wave_all<R_MIN>(gs), hi = mc;
@@ -98,7 +97,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
       }
       if (mc - mnc < kWaveMaxRange) {
         // (the exact counts look at this first chunk only: the rest of the row has not been read yet)
-        if (!wave_threshold_check<T, VEC, false>(v, F, mnc, mc, hi)) slow = true;
+        if (!wave_threshold_check<T, VEC, LW>(v, F, mnc, mc, hi)) slow = true;
       }
       t1p = hi - mp;
       if (!(t1p < 0.0)) slow = true;
@@ -111,7 +110,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
     const double xpad = mn_run - mp;
     if (last) {
       if (key_of(xpad) >= key_of(t1p)) slow = true;  // pads would be counted as candidates
-      pad_tail<T, VEC, NQ - 1, true>(v, qfull, qrem, (T)(-mn_run));
+      pad_tail<T, VEC, NQ - 1, true>(v, qfull, qrem, LW ? (T)mn_run : (T)(-mn_run));
     }
     // ---- sweep of the chunk (pla_wave.h, section 2) -------------------------------------------------
     double nl256 = -kLn2_256, c6 = 1.66666666666666666667e-01;
@@ -120,7 +119,8 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
     int four = 4;
     asm volatile("" : "+v"(four));
     // what streams in behind the sweep: the next chunk of this row, or the first chunk of the next row
-    const T* rp_stream = last ? rp_next : row + (int64_t)(ch + 1) * kChunkDraws;
+    // (weights mode: the row's own first chunk again, for the output pass)
+    const T* rp_stream = last ? (LW ? row : rp_next) : row + (int64_t)(ch + 1) * kChunkDraws;
     int bytes_stream = 0;
     if (rp_stream) {
       const int left = last ? S : S - (ch + 1) * kChunkDraws;
@@ -128,6 +128,8 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
     }
     const __amdgpu_buffer_rsrc_t rs_next = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>(rp_stream ? rp_stream : row), 0, bytes_stream, 0x00020000);
+    int id_base = VEC * lane + ch * kChunkDraws;
+    asm volatile("" : "+v"(id_base));
     constexpr int kPF = 3;
     double px[kPF], pt[kPF];
     int4 ptt[kPF];
@@ -147,7 +149,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
       }
       if (i < EPT) {  // stage A of draw i
         const int sl = i % kPF;
-        const double x = (-(double)v[i]) - shift;
+        const double x = LW ? (double)v[i] - shift : (-(double)v[i]) - shift;
         const double t = fma(x, c256, magic);
         const int k = __double2loint(t);
         px[sl] = x;
@@ -159,6 +161,9 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
         unsigned pos8 = (rank << 3) + base8;
         asm("" : "+v"(pos8));
         lds_store(cand ? pos8 : dump8, (double)v[i]);  // the INPUT value: x = -value - m follows after the last chunk
+        if constexpr (LW)  // draw index of the candidate: 4096 ch + VEC * (lane + 64 q) + e for slot i = q VEC + e
+          sm.ids[cand ? ((pos8 - cand0) >> 3) : (unsigned)(kCand + kWave + lane)] =
+              (unsigned short)(id_base + (VEC * kWave * (i / VEC) + i % VEC));
         {
           const unsigned pc = (unsigned)__popcll(cm);
           asm("s_lshl3_add_u32 %0, %1, %0" : "+s"(next8) : "s"(pc) : "scc");
@@ -190,7 +195,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
   wave_sync();
   if (!slow && ((int)ncand < M + 1 || ncand > (unsigned)kCand)) slow = true;
   if (!slow) {
-    for (unsigned c = lane; c < ncand; c += kWave) sm.cand[c] = (-sm.cand[c]) - m;  // psis.py:134, one rounding
+    for (unsigned c = lane; c < ncand; c += kWave) sm.cand[c] = LW ? sm.cand[c] - m : (-sm.cand[c]) - m;  // psis.py:134, one rounding
     s1 *= exp_tab(-delta, tb.tab);  // e^x = e^x' e^-(m - m');  s2 is rescaled in log space (lppd_shift)
     // histogram origin one key below the threshold: x and the threshold were rounded on different paths
     const int k1 = key_of(t1p - delta) - 1;
@@ -205,9 +210,31 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
       wave_select_split<SM, TB, (SM::Caps::kMaxTail + 63) / 64>(F, sm, tb, r, lane, M, m, mn, s1, s2, ncand, k1, sh, magic, c256, slow,
                                                                 CandInLds<SM>{sm});
     } else {
-      wave_back<T, VEC, LW, SM, TB>(P, sm, tb, r, v, lane, S, M, mestM, logS, dbgs, m, mn, R, delta, s1, s2, ncand, k1, sh,
-                                    magic, c256, nvl / kWave, nvl % kWave, slow, khat, loo, lppd);
+      wave_back<T, VEC, LW, SM, TB, false, LW>(P, sm, tb, r, v, lane, S, M, mestM, logS, dbgs, m, mn, R, delta, s1, s2, ncand, k1,
+                                               sh, magic, c256, nvl / kWave, nvl % kWave, slow, khat, loo, lppd);
     }
+  }
+  if constexpr (LW) {
+    // ---- weights mode: the row passes through the registers once more (its first chunk came in behind the last sweep),
+    // each vector stored as lw = (raw - m) - L and replaced by the same vector of the following chunk; then the smoothed tail
+    if (!slow) {
+      const double L = loo;
+      T* orow = reinterpret_cast<T*>(P.lw_out) + r * (int64_t)S;
+#pragma unroll 1
+      for (int ch = 0; ch < nch; ++ch) {
+        const int Sc = (S - ch * kChunkDraws < kChunkDraws) ? S - ch * kChunkDraws : kChunkDraws;
+        const int left = S - (ch + 1) * kChunkDraws;  // draws after this chunk
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(orow + (int64_t)ch * kChunkDraws, 0, Sc * (int)sizeof(T), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_next = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<T*>(row + (int64_t)(ch + 1 < nch ? ch + 1 : 0) * kChunkDraws), 0,
+            left > 0 ? (left < kChunkDraws ? left : kChunkDraws) * (int)sizeof(T) : 0, 0x00020000);
+        lw_store_chunk<T, VEC, true>(v, ro, rs_next, lane, (Sc / VEC) / kWave, m_run, L);
+      }
+      const int ntail = (int)lppd;
+      if (ntail > 0) lw_patch_tail<T>(sm, tb, orow, lane, ntail, L);
+    }
+    // the next row's first chunk (weights mode never streams it behind the sweep)
+    if (rp_next) issue_row_loads<T, VEC, 0>(v, rp_next, S < kChunkDraws ? S : kChunkDraws);
   }
   if (lane == 0) {
     if (slow) {
@@ -218,15 +245,17 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
       double *pd = P.diag, *pl = P.loo_i, *pp = P.lppd_i;
       asm volatile("" : "+s"(pd), "+s"(pl), "+s"(pp));  // (null tests inside the row loop, not hoisted into scalar registers it lacks)
       if (pd) pd[r] = khat;
-      if (pl) pl[r] = P.scale_value * loo;
-      if (pp) pp[r] = lppd;
+      if constexpr (!LW) {
+        if (pl) pl[r] = P.scale_value * loo;
+        if (pp) pp[r] = lppd;
+      }
     }
   }
 }
 
-template <typename T, int VEC, class CAP, bool SPLIT = false>
+template <typename T, int VEC, class CAP, bool SPLIT = false, bool LW = false>
 __global__ __launch_bounds__(kWave * CAP::kWaves, 1) void wave_loo_chunked_kernel(RowsParams P, FastParams F) {
-  using SM = WaveSmemT<CAP>;
+  using SM = std::conditional_t<LW, WaveSmemLWT<CAP>, WaveSmemT<CAP>>;
   using TB = std::conditional_t<SPLIT, WaveTabOnly, WaveTablesT<CAP>>;
   constexpr int kWavesPerBlock = CAP::kWaves;
   __shared__ __attribute__((aligned(16))) SM scratch[kWavesPerBlock];
@@ -250,7 +279,7 @@ __global__ __launch_bounds__(kWave * CAP::kWaves, 1) void wave_loo_chunked_kerne
   for (int64_t r = w0; r < P.n_obs; r += nw) {
     const int64_t rn = r + nw;
     const T* nxt = rn < P.n_obs ? base + PLA_ROW_OFFSET(P, rn) : nullptr;
-    wave_loo_row_chunked<T, VEC, SM, TB, SPLIT>(P, F, sm, tb, r, v, cur, nxt);
+    wave_loo_row_chunked<T, VEC, SM, TB, SPLIT, LW>(P, F, sm, tb, r, v, cur, nxt);
     cur = nxt;
   }
 }

@@ -328,7 +328,7 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, co
 }
 
 // long rows (chunks of 4096 draws) and / or tail counts up to 512: pla_chunked.h
-template <typename T, int VEC, class CAP>
+template <typename T, int VEC, class CAP, bool LW = false>
 static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, int bits, const ThresholdCheck& chk, hipStream_t stream,
                                  hipEvent_t after_first, bool* recorded) {
   hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
@@ -345,9 +345,9 @@ static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, int bits,
   int64_t grid = (p.n_obs + W - 1) / W;
   if (grid > 2048 * 8 / W) grid = 2048 * 8 / W;
   bool split = false;
-  if constexpr (CAP::kMaxTail <= 448) split = !fused && split_ok(p, mestM) && p.ws_stride <= 64 * ((CAP::kMaxTail + 63) / 64);
+  if constexpr (CAP::kMaxTail <= 448 && !LW) split = !fused && split_ok(p, mestM) && p.ws_stride <= 64 * ((CAP::kMaxTail + 63) / 64);
   if (split) {
-    if constexpr (CAP::kMaxTail <= 448) {
+    if constexpr (CAP::kMaxTail <= 448 && !LW) {
       f.ws_y = p.ws_y;
       f.ws_s = p.ws_s;
       f.ws_stride = p.ws_stride;
@@ -359,7 +359,7 @@ static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, int bits,
       if (e != hipSuccess) return e;
     }
   } else {
-    hipLaunchKernelGGL((wave_loo_chunked_kernel<T, VEC, CAP>), dim3((unsigned)grid), dim3(kWave * W), 0, stream, p, f);
+    hipLaunchKernelGGL((wave_loo_chunked_kernel<T, VEC, CAP, false, LW>), dim3((unsigned)grid), dim3(kWave * W), 0, stream, p, f);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -368,10 +368,10 @@ static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, int bits,
   int64_t g2 = p.n_obs < 1024 ? p.n_obs : 1024;
   if (p.n_draws >= 8192) {
     constexpr int BLOCK = 1024;
-    hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK, false>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap), stream, p);
+    hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK, LW>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap), stream, p);
   } else {
     constexpr int BLOCK = 256;
-    hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK, false>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap), stream, p);
+    hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK, LW>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap), stream, p);
   }
   return hipGetLastError();
 }
@@ -419,19 +419,31 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream, hipEvent
       if (path != 1 && unit && waligned && (p.method == PLA_SIS || p.method == PLA_TIS) && p.slow_list && p.counters &&
           p.n_draws <= kWave * kWaveSlots && p.n_draws >= kWave * WVEC && p.n_obs <= 0xffffffffll)
         return launch_is<T, WVEC>(p, stream);
+    }
+    {
       // rows beyond one register chunk or tails beyond the small kernel's LDS: the chunked kernel
+      // (weights mode: the candidates carry 16-bit draw indices, so rows up to 65 536 draws; two LDS capacities)
       const int last_chunk = p.n_draws - ((p.n_draws - 1) / kChunkDraws) * kChunkDraws;
       if (path != 1 && unit && waligned && p.method == PLA_PSIS && p.slow_list && p.counters && p.l1_table &&
           p.n_draws >= 256 && p.n_draws <= (1 << 20) && last_chunk >= kWave * WVEC && p.tail_count <= CapsBig::kMaxTail &&
-          smem_bytes(BLOCK, p.tail_cap) <= 64 * 1024 && p.n_obs <= 0xffffffffll) {
+          (!LW || p.n_draws <= 65536) && smem_bytes(BLOCK, p.tail_cap) <= 64 * 1024 && p.n_obs <= 0xffffffffll) {
         int gsz = 0, kq = 0, bits = 0;
         ThresholdCheck chk{};
+        if constexpr (LW) {
+          // (f32 rows: six waves per CU; f64 rows need more than 256 registers per lane next to the row, so four)
+          using CapLW = std::conditional_t<sizeof(T) == 4, CapsMidLW, CapsMid>;
+          if (p.tail_count <= CapLW::kMaxTail && wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk, CapLW::kCand))
+            return launch_chunked<T, WVEC, CapLW, true>(p, gsz, kq, bits, chk, stream, after_first, recorded);
+          if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk, CapsBig::kCand))
+            return launch_chunked<T, WVEC, CapsBig, true>(p, gsz, kq, bits, chk, stream, after_first, recorded);
+        } else {
         if (p.tail_count <= CapsMid4::kMaxTail && wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk, CapsMid4::kCand))
           return launch_chunked<T, WVEC, CapsMid4>(p, gsz, kq, bits, chk, stream, after_first, recorded);
         if (p.tail_count <= CapsMid::kMaxTail && wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk, CapsMid::kCand))
           return launch_chunked<T, WVEC, CapsMid>(p, gsz, kq, bits, chk, stream, after_first, recorded);
         if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk, CapsBig::kCand))
           return launch_chunked<T, WVEC, CapsBig>(p, gsz, kq, bits, chk, stream, after_first, recorded);
+        }
       }
     }
     if (path == 1) return launch_one<T, BLOCK, 0, LW>(p, stream);

@@ -102,6 +102,12 @@ struct CapsMid {                                    // chunked rows with M <= 44
 struct WaveTabOnly {
   double tab[2 * kTabN];
 };
+struct CapsMidLW {                                  // weights mode of the chunked kernel: CapsMid's capacities + the candidates' draw indices,
+  static constexpr int kCand = 1280;                // six waves in ONE workgroup per CU (156 KB of LDS with the four tables)
+  static constexpr int kSa = 512;
+  static constexpr int kMaxTail = 448;
+  static constexpr int kWaves = 6;
+};
 struct CapsMid4 {                                   // M <= 320 (S up to ~11 000 at reff = 1, or reff >= 0.35 at S = 4000): 8 waves per CU
   static constexpr int kCand = 1088;
   static constexpr int kSa = 512;
@@ -480,7 +486,50 @@ __device__ __forceinline__ bool wave_threshold_check(const T (&v)[kWaveSlots], c
 // Everything after the sweep: exact selection of the M+1 largest among the candidates, GPD fit,
 // smoothing sums and the outputs.  Shared by the one-chunk and the chunked front ends; `lppd_shift` is
 // the log of the factor by which the chunked front's s2 is short (0 otherwise).
-template <typename T, int VEC, bool LW, typename SM, typename TB, bool SPLIT = false>
+// ---- weights mode, output: lw_s = (raw_s - m) - L for the (up to) 4096 draws held in the row registers, 16 bytes per lane
+// and store (stores past the end of `ro` are dropped).  STREAM: once a vector is stored, the same registers take the vector of
+// the next chunk from `rs_next` (chunked kernel: the row passes through the registers a second time).
+template <typename T, int VEC, bool STREAM>
+__device__ __forceinline__ void lw_store_chunk(T (&v)[kWaveSlots], const __amdgpu_buffer_rsrc_t ro, const __amdgpu_buffer_rsrc_t rs_next,
+                                               const int lane, const int qfull, const double m, const double L) {
+  constexpr int NQ = kWaveSlots / VEC;
+  typedef int v4i __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    if (q <= qfull) {  // later vectors lie past the row (stores past the end are dropped anyway)
+      v4i t;
+      if constexpr (VEC == 2) {
+        const double a0 = ((double)v[2 * q] - m) - L, a1 = ((double)v[2 * q + 1] - m) - L;
+        t[0] = __double2loint(a0); t[1] = __double2hiint(a0);
+        t[2] = __double2loint(a1); t[3] = __double2hiint(a1);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = __float_as_int((float)(((double)v[4 * q + e] - m) - L));
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(t, ro, lane * 16, q * (kWave * 16), 0);  // (non-temporal stores measured 5 % slower)
+      // gfx9 hazard: a VALU write to the data registers of a > 8-byte buffer store with an SGPR offset
+      // needs a wait state after the store.  The compiler's hazard pass misses it across the block
+      // boundary that follows the last store (observed: the low dword of the stored value replaced
+      // by the next instruction's literal), so the registers are kept alive over one s_nop.
+      asm volatile("s_nop 0" : : "v"(t));
+    }
+    if constexpr (STREAM) issue_row_vector<T, VEC>(v, rs_next, q);
+  }
+}
+// the smoothed tail at its positions (psis.py:155-158); must land after the row's stores
+template <typename T, class SM, class TB>
+__device__ __forceinline__ void lw_patch_tail(SM& sm, const TB& tb, T* orow, const int lane, const int n, const double L) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const double* wtail = sm.cand + SM::Caps::kSa + kWave;
+  for (int j = lane; j < n; j += kWave) {
+    const int id = (int)sm.sb_id[n - 1 - j];
+    orow[id] = (T)(log_tab(wtail[j], tb.lt) - L);
+  }
+}
+
+// (DEFER, weights mode of the chunked kernel: the row is not in the registers, so nothing is stored here; `loo` returns
+// L = log(total) and `lppd` the smoothed tail length (0: nothing to patch) for lw_store_chunk / lw_patch_tail below)
+template <typename T, int VEC, bool LW, typename SM, typename TB, bool SPLIT = false, bool DEFER = false>
 __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB& tb, const int64_t r, T (&v)[kWaveSlots],
                                           const int lane, const int S, const int M, const int mestM, const double logS,
                                           const int dbgs, const double m, const double mn, const double R,
@@ -917,36 +966,14 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
       if (!(total > 1e-280) || !isfinite(L)) {
         slow = true;
       } else {
-        typedef int v4i __attribute__((ext_vector_type(4)));
-        T* orow = reinterpret_cast<T*>(P.lw_out) + r * (int64_t)S;
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(orow, 0, S * (int)sizeof(T), 0x00020000);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          if (q <= qfull) {  // later vectors lie past the row (stores past the end are dropped anyway)
-            v4i t;
-            if constexpr (VEC == 2) {
-              const double a0 = ((double)v[2 * q] - m) - L, a1 = ((double)v[2 * q + 1] - m) - L;
-              t[0] = __double2loint(a0); t[1] = __double2hiint(a0);
-              t[2] = __double2loint(a1); t[3] = __double2hiint(a1);
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) t[e] = __float_as_int((float)(((double)v[4 * q + e] - m) - L));
-            }
-            __builtin_amdgcn_raw_buffer_store_b128(t, ro, lane * 16, q * (kWave * 16), 0);  // (non-temporal stores measured 5 % slower)
-            // gfx9 hazard: a VALU write to the data registers of a > 8-byte buffer store with an SGPR offset
-            // needs a wait state after the store.  The compiler's hazard pass misses it across the block
-            // boundary that follows the last store (observed: the low dword of the stored value replaced
-            // by the next instruction's literal), so the registers are kept alive over one s_nop.
-            asm volatile("s_nop 0" : : "v"(t));
-          }
-        }
-        if (smoothed) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the patches below must land after the row
-          const double* wtail = sb + kSa + kWave;
-          for (int j = lane; j < n; j += kWave) {
-            const int id = (int)sm.sb_id[n - 1 - j];
-            orow[id] = (T)(log_tab(wtail[j], tb.lt) - L);  // psis.py:155-158
-          }
+        if constexpr (DEFER) {
+          loo = L;
+          lppd = smoothed ? (double)n : 0.0;
+        } else {
+          T* orow = reinterpret_cast<T*>(P.lw_out) + r * (int64_t)S;
+          const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(orow, 0, S * (int)sizeof(T), 0x00020000);
+          lw_store_chunk<T, VEC, false>(v, ro, ro, lane, qfull, m, L);
+          if (smoothed) lw_patch_tail<T>(sm, tb, orow, lane, n, L);
         }
       }
     } else {

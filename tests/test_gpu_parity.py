@@ -421,6 +421,19 @@ def test_chunked_kernel_vs_oracle(eng, S, N, reff, dt):
     n_slow = int(res["agg"][7])
     assert 4 <= n_slow <= 12, n_slow          # nan, -inf, wide, constant, dominant draw (+ threshold misses / ties)
     np.testing.assert_allclose(res["agg"][1], ref["elpd_loo"], rtol=RTOL)
+    # weights mode of the same kernel (psislw on long rows): the row passes through the registers a second time
+    lw, kk = eng.importance_weights(-ll, M, "psis")
+    close(kk, ref["khat"], what="khat(lw)")
+    want = ref["lw"].copy()
+    for i in range(N):                        # tied tail draws: same multiset of weights, their order is the sort's (see above)
+        if has_tail_ties(ll[i], M):
+            lw[i], want[i] = np.sort(lw[i]), np.sort(want[i])
+    if dt == np.float64:
+        close(lw, want, what="lw")
+    else:
+        close(lw, want.astype(np.float32), rtol=2e-7, atol=1e-7, what="lw (f32 output)")
+    ok = ~np.isnan(lw).any(axis=1)
+    np.testing.assert_allclose(np.exp(lw[ok].astype(np.float64)).sum(axis=1), 1.0, rtol=1e-5 if dt == np.float32 else 1e-10)
 
 
 def test_general_kernel_agrees_with_fast_path():

@@ -24,8 +24,10 @@ KERNELS = {
     "wave_loo_chunked_kernelIdLi2ENS_8CapsMid4ELb1": 81920,   # long rows / small reff, split pass (production)
     "wave_loo_chunked_kernelIfLi4ENS_7CapsMidELb1": 81920,    # C5: S = 20 000 f32, M = 425
     "fit_rows_kernelILi7ELi4ELi2": 81920,                     # its fit half (448-value tails, 64-point grid)
-    "wave_loo_chunked_kernelIdLi2ENS_8CapsMid4ELb0": 81920,   # fused fallbacks (no workspace / M > 448)
-    "wave_loo_chunked_kernelIfLi4ENS_7CapsMidELb0": 163840,   # (this fallback carries the fit's tables too: one workgroup per CU)
+    "wave_loo_chunked_kernelIdLi2ENS_8CapsMid4ELb0ELb0": 81920,   # fused fallbacks (no workspace / M > 448)
+    "wave_loo_chunked_kernelIfLi4ENS_7CapsMidELb0ELb0": 163840,   # (this fallback carries the fit's tables too: one workgroup per CU)
+    "wave_loo_chunked_kernelIfLi4ENS_9CapsMidLWELb0ELb1": 163840,   # weights mode for long rows (psislw, S > 4096): one workgroup per CU
+    "wave_loo_chunked_kernelIdLi2ENS_7CapsMidELb0ELb1": 163840,
     "waic_wave_kernelIdLi2": 81920,
     "is_wave_kernelIdLi2ELb0": 81920,
     "is_wave_kernelIdLi2ELb1": 81920,
@@ -40,8 +42,9 @@ def test_row_kernels_do_not_spill(tmp_path):
     for pat, lds_limit in KERNELS.items():
         name, total, _, res = isa_stats.kernel_stats(lines, pat)
         assert res.get("ScratchSize", 0) == 0, (name, res)
-        # (the fused chunked fallbacks keep ONE hoisted LDS offset in a vector lane: no scratch next to it, checked above)
-        assert total.get("v_writelane_b32", 0) <= (1 if "chunked" in pat and pat.endswith("ELb0") else 0), (name, dict(total))
+        # (the fused chunked kernels keep a few hoisted scalars in vector lanes: no scratch next to them, checked above)
+        allowed = 4 if pat.endswith("ELb0ELb1") else 1 if pat.endswith("ELb0ELb0") else 0
+        assert total.get("v_writelane_b32", 0) <= allowed, (name, dict(total))
         assert not any(k.startswith("scratch_") for k in total), (name, dict(total))
         assert res.get("NumVgprs", 0) <= 256 and res.get("Occupancy", 0) >= 1, (name, res)
         assert res.get("LDSByteSize", 0) <= lds_limit, (name, res)  # two workgroups per CU (160 KB LDS)
