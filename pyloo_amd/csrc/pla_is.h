@@ -7,8 +7,8 @@
 //   A = sum e^x_t,  B = sum e^(2 x_t),  D = sum e^(x_t - x),  C = sum e^-x
 //   ESS = A^2 / B,   loo_i = -max - log A + log D,   lppd_i = log C - max - log S
 // (SIS: x_t = x, D = S).  One wavefront per observation, the row in its registers (S <= 4096, unit
-// draw stride, 16-byte aligned rows): one HBM read; TIS makes a second pass over the registers, the
-// next row streams in behind the last pass.  Rows with non-finite entries or more than 690 nats of
+// draw stride, 16-byte aligned rows): one HBM read; TIS looks through the registers once more for the (few) draws above
+// the truncation point; the next row streams in behind the last pass.  Rows with non-finite entries or more than 690 nats of
 // range go to the general kernel through the device list, as in pla_wave.h.
 #pragma once
 
@@ -98,32 +98,47 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void is_wave_kernel(Rows
     if constexpr (!tis) {
       B = wave_all<R_SUM>(sb);
     } else {
-      // ---- pass 2 (TIS): truncate at cut = LSE(x) - log S + 0.5 log S, sums of the truncated weights ----
-      const double cut = (log_tab(A, lt) - log_S) + 0.5 * log_S;  // tis.py:107-110
+      // ---- pass 2 (TIS): truncate at cut = LSE(x) - log S + 0.5 log S (tis.py:107-110) ---------------------------
+      // At most sqrt(S) draws can lie above the cut (their weights exceed A / sqrt(S) and sum to at most A), so the pass does
+      // not evaluate the row again: one compare per slot finds them, and what truncation takes away from them is subtracted
+      // from the sums of pass 1 --  A_t = A - sum_tr (e^x - e^cut),  B_t = B - sum_tr (e^2x - e^2cut),
+      // D = S - sum_tr (1 - e^(cut - x))  -- with the SAME exponentials pass 1 added, so exactly those leave.  Nothing
+      // cancels badly: A_t >= A / sqrt(S) and B_t >= A^2 / S >= B / S keep all but ~4 of the 16 digits.
+      const double cut = (log_tab(A, lt) - log_S) + 0.5 * log_S;
       const double ecut = exp_tab(fmin(fmax(cut, -700.0), 700.0), tab);
-      double ta = 0.0, tb = 0.0, td = 0.0;
-      double m2 = m;  // laundered: otherwise the 64 shifted values of pass 1 are kept alive for this pass and spill
+      B = wave_all<R_SUM>(sb);
+      double m2 = m;
       asm volatile("" : "+v"(m2));
-      const auto term = [&](double x, double& a, double& b, double& d) {
+      // v < thr  <=>  (-v) - m > cut, up to the rounding of the subtraction: thr is widened, the exact test follows inside
+      const double thr0 = -(m2 + cut);
+      const double thr = thr0 + fmax(fabs(thr0), fabs(m2)) * 1e-12;
+      double da = 0.0, db = 0.0, dd = 0.0;
+      const auto term = [&](double x, double& a, double& b2, double& d) {
         double ep, en;
         exp_pair(x, tab, ep, en);
         const bool tr = x > cut;
-        const double w = tr ? ecut : ep;
-        a += w;
-        b = fma(w, w, b);
-        d += tr ? ecut * en : 1.0;
+        a += tr ? ep - ecut : 0.0;
+        b2 += tr ? fma(ep, ep, -ecut * ecut) : 0.0;
+        d += tr ? fma(-ecut, en, 1.0) : 0.0;
       };
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
-        term((-(double)v[i]) - m2, ta, tb, td);
-        if ((i & 1) == 1) asm volatile("" : "+v"(ta), "+v"(tb), "+v"(td));
+        if (__ballot((double)v[i] < thr) != 0ull) term((-(double)v[i]) - m2, da, db, dd);
         if ((i % VEC) == VEC - 1) issue_row_vector<T, VEC>(v, rs_next, i / VEC);
       }
-      double a0 = 0.0, b0 = 0.0, d0 = 0.0;
+      {  // the padded slots hold copies of the lane's first vector
+        double a0 = 0.0, b0 = 0.0, d0 = 0.0;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) term(first[e] - m2, a0, b0, d0);
-      A = wave_all<R_SUM>(fma(-ncopy, a0, ta));
-      wave_all2<R_SUM>(fma(-ncopy, b0, tb), fma(-ncopy, d0, td), B, D);
+        for (int e = 0; e < VEC; ++e) term(first[e] - m2, a0, b0, d0);
+        da = fma(-ncopy, a0, da);
+        db = fma(-ncopy, b0, db);
+        dd = fma(-ncopy, d0, dd);
+      }
+      double sda, sdb;
+      wave_all2<R_SUM>(da, db, sda, sdb);
+      A -= sda;
+      B -= sdb;
+      D -= wave_all<R_SUM>(dd);
     }
     ess = div_fast(A * A, B);
     const double lg = log_tab(lane == 1 ? C : (lane == 2 ? D : A), lt);
