@@ -875,9 +875,11 @@ int pla_e_loo(pla_engine* eng, const void* x, const void* log_weights, const voi
   EngineCall call(eng);
   PLA_HIP(hipSetDevice(eng->device));
   hipStream_t s = (hipStream_t)stream;
+  // (row list of the one-pass wave kernel: the rows it leaves to the general one)
+  if (int rc0 = grow(&eng->d_slow, &eng->d_slow_bytes, (size_t)n_obs * sizeof(unsigned))) return rc0;
   if (mem_space == PLA_DEVICE) {
     PLA_HIP(pla::launch_e_loo(x, log_weights, log_ratios, dtype, n_obs, (int)n_draws, stride_obs, stride_draw, (int)tail_len, mean,
-                              variance, k_mean, k_var, k_ratio, s));
+                              variance, k_mean, k_var, k_ratio, (unsigned*)eng->d_slow, eng->counters, s));
     return PLA_OK;
   }
   // ---- PLA_HOST: row blocks of the two or three matrices through the staging buffers (d_in: x, d_lw: log-weights, d_slab: ratios)
@@ -907,7 +909,7 @@ int pla_e_loo(pla_engine* eng, const void* x, const void* log_weights, const voi
       PLA_HIP(hipMemcpy2DAsync(eng->d_slab, row_bytes, (const char*)log_ratios + off, pitch, row_bytes, (size_t)nr, hipMemcpyHostToDevice, s));
     double* d = eng->d_pw;
     PLA_HIP(pla::launch_e_loo(eng->d_in, eng->d_lw, log_ratios ? eng->d_slab : nullptr, dtype, nr, (int)n_draws, n_draws, 1, (int)tail_len,
-                              d, d + nr, d + 2 * nr, d + 3 * nr, d + 4 * nr, s));
+                              d, d + nr, d + 2 * nr, d + 3 * nr, d + 4 * nr, (unsigned*)eng->d_slow, eng->counters, s));
     for (int k = 0; k < 5; ++k)
       if (out[k]) PLA_HIP(hipMemcpyAsync(out[k] + r0, d + k * nr, (size_t)nr * sizeof(double), hipMemcpyDeviceToHost, s));
     PLA_HIP(hipStreamSynchronize(s));  // the staging buffers are reused by the next block

@@ -24,6 +24,7 @@
 #pragma once
 
 #include "pla_math.h"
+#include "pla_wave.h"
 
 namespace pla {
 
@@ -40,6 +41,9 @@ struct ELooParams {
   double* k_mean;  // [n_obs] or null: k_hat(x, lr)
   double* k_var;   // [n_obs] or null: k_hat(x^2, lr)
   double* k_none;  // [n_obs] or null: k_hat(None, lr)
+  // fast path (e_loo_wave_kernel) -> general kernel hand-over: rows the former declines, and how many
+  unsigned* slow_list;
+  unsigned long long* slow_count;
 };
 
 constexpr double kCloseRtol = 1e-5, kCloseAtol = 1e-8;  // np.allclose / np.isclose defaults
@@ -84,14 +88,56 @@ __device__ __forceinline__ void block_reduce_k(double (&v)[K], const int (&op)[K
   }
 }
 
-template <typename T, int BLOCK>
+// everything that follows the row's sums, extremes and counts (one lane): expectations (e_loo.py:437, 518-531) and k_hat's guards
+__device__ __forceinline__ void e_loo_finish(const ELooParams& P, const int64_t r, const int n_tail, const unsigned flags, const double sa,
+                                             const double sb, const double sc, const double sd, const double x0, const double q0,
+                                             const double xdev, const double qdev, const double xmn, const double xmx, const double qmn,
+                                             const double qmx, const bool two_x, const bool two_q, const double n_valid,
+                                             const double n_close_r, const double c1l, const double c1r, const double c2l,
+                                             const double c2r) {
+  // ---- expectations ----
+  const double mean = sb / sa, msq = sc / sa, wss = sd / (sa * sa);
+  if (P.mean) P.mean[r] = mean;
+  if (P.var) {
+    double v;
+    if (xdev <= kCloseAtol + kCloseRtol * fabs(x0) && !(flags & 4u)) v = 0.0;      // e_loo.py:520-521
+    else if (fabs(wss - 1.0) <= kCloseAtol + kCloseRtol * 1.0) v = 0.0;             // 523-525
+    else {
+      v = (msq - mean * mean) / (1.0 - wss);                                          // 527-530
+      v = (0.0 > v) ? 0.0 : v;  // Python's max(var, 0.0): a NaN variance stays NaN    531
+    }
+    P.var[r] = v;
+  }
+  // ---- k_hat ----
+  const double k_r = tail_piece(n_tail, n_valid, n_close_r, pinf());                 // 353-357
+  const auto k_of = [&](bool skip, double n_left, double n_right) {
+    if (skip) return k_r;                                                             // 359-366
+    const double kl = tail_piece(n_tail, n_valid, n_left, -pinf());                  // 373-377
+    const double kr = tail_piece(n_tail, n_valid, n_right, -pinf());                 // 379-383
+    const double k_hr = py_max(kl, kr);                                               // 385
+    if (k_hr != k_hr && k_r != k_r) return qnan();                                    // 387-388
+    return py_max(k_hr, k_r);                                                         // 390
+  };
+  const bool skip_x = (xdev <= kCloseAtol + kCloseRtol * fabs(x0) && !(flags & 4u)) || (two_x && xmn != xmx && !(flags & 4u)) ||
+                      (flags & (4u | 8u)) != 0u;
+  const bool skip_q = (qdev <= kCloseAtol + kCloseRtol * fabs(q0) && !(flags & 4u)) || (two_q && qmn != qmx && !(flags & 4u)) ||
+                      (flags & (4u | 16u)) != 0u;
+  if (P.k_mean) P.k_mean[r] = k_of(skip_x, c1l, c1r);
+  if (P.k_var) P.k_var[r] = k_of(skip_q, c2l, c2r);
+  if (P.k_none) P.k_none[r] = k_r;
+}
+
+// LIST: the rows of P.slow_list (what the wave kernel below declined) instead of all of them
+template <typename T, int BLOCK, bool LIST = false>
 __global__ __launch_bounds__(BLOCK) void e_loo_rows_kernel(ELooParams P) {
   __shared__ double red[(BLOCK / kWave) * 12];
   const int tid = threadIdx.x;
   const int S = P.n_draws;
   const int n_tail = S < P.tail_len ? S : P.tail_len;
   const bool own_lr = P.lr != P.lw;
-  for (int64_t r = blockIdx.x; r < P.n_obs; r += gridDim.x) {
+  const int64_t n_rows = LIST ? (int64_t)*P.slow_count : P.n_obs;
+  for (int64_t ri = blockIdx.x; ri < n_rows; ri += gridDim.x) {
+    const int64_t r = LIST ? (int64_t)P.slow_list[ri] : ri;
     const T* xr = reinterpret_cast<const T*>(P.x) + r * P.stride_obs;
     const T* wr = reinterpret_cast<const T*>(P.lw) + r * P.stride_obs;
     const T* rr = reinterpret_cast<const T*>(P.lr) + r * P.stride_obs;
@@ -183,38 +229,240 @@ __global__ __launch_bounds__(BLOCK) void e_loo_rows_kernel(ELooParams P) {
       block_reduce_k<4, BLOCK>(a, op, red);
       c1l = a[0]; c1r = a[1]; c2l = a[2]; c2r = a[3];
     }
-    if (tid == 0) {
-      // ---- expectations ----
-      const double mean = sb / sa, msq = sc / sa, wss = sd / (sa * sa);
-      if (P.mean) P.mean[r] = mean;
-      if (P.var) {
-        double v;
-        if (xdev <= kCloseAtol + kCloseRtol * fabs(x0) && !(flags & 4u)) v = 0.0;      // e_loo.py:520-521
-        else if (fabs(wss - 1.0) <= kCloseAtol + kCloseRtol * 1.0) v = 0.0;             // 523-525
-        else {
-          v = (msq - mean * mean) / (1.0 - wss);                                          // 527-530
-          v = (0.0 > v) ? 0.0 : v;  // Python's max(var, 0.0): a NaN variance stays NaN    531
-        }
-        P.var[r] = v;
-      }
-      // ---- k_hat ----
-      const double k_r = tail_piece(n_tail, n_valid, n_close_r, pinf());                 // 353-357
-      const auto k_of = [&](bool skip, double n_left, double n_right) {
-        if (skip) return k_r;                                                             // 359-366
-        const double kl = tail_piece(n_tail, n_valid, n_left, -pinf());                  // 373-377
-        const double kr = tail_piece(n_tail, n_valid, n_right, -pinf());                 // 379-383
-        const double k_hr = py_max(kl, kr);                                               // 385
-        if (k_hr != k_hr && k_r != k_r) return qnan();                                    // 387-388
-        return py_max(k_hr, k_r);                                                         // 390
-      };
-      const bool skip_x = (xdev <= kCloseAtol + kCloseRtol * fabs(x0) && !(flags & 4u)) || (other_x == 0.0 && xmn != xmx && !(flags & 4u)) ||
-                          (flags & (4u | 8u)) != 0u;
-      const bool skip_q = (qdev <= kCloseAtol + kCloseRtol * fabs(q0) && !(flags & 4u)) || (other_q == 0.0 && qmn != qmx && !(flags & 4u)) ||
-                          (flags & (4u | 16u)) != 0u;
-      if (P.k_mean) P.k_mean[r] = k_of(skip_x, c1l, c1r);
-      if (P.k_var) P.k_var[r] = k_of(skip_q, c2l, c2r);
-      if (P.k_none) P.k_none[r] = k_r;
+    if (tid == 0)
+      e_loo_finish(P, r, n_tail, flags, sa, sb, sc, sd, x0, q0, xdev, qdev, xmn, xmx, qmn, qmx, other_x == 0.0, other_q == 0.0, n_valid,
+                   n_close_r, c1l, c1r, c2l, c2r);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fast path: one WAVEFRONT per observation, ONE pass over the two or three rows (unit draw stride, 16-byte vectors).
+//   * the weights are accumulated against a running, wave-uniform maximum of the log-weights (a ballot-guarded branch
+//     rescales the four sums when a lane meets a larger one: a handful of times per row once the first 64 vectors are in);
+//     the ratios r likewise (OWN: their own maximum and exponential; otherwise r is the weight itself);
+//   * what k_hat's guards need from the ORDER of the draws -- are there n values allclose to the extreme? -- is decided
+//     from the two most extreme values of each quantity (largest log ratio; smallest and largest of x r and x^2 r), kept
+//     per lane with a min/max pair: when the runner-up is outside the tolerance, exactly one value is "close" and no count
+//     is needed.  Otherwise (ties, constant weights, a heap of x r below the absolute tolerance) the wave counts, in a
+//     second pass over rows that are still in the caches;
+//   * "h has exactly two distinct values" (e_loo.py:362-363) is tracked per lane as {lo, hi, saw-a-third} and settled
+//     across the lanes against the row's minimum and maximum: exact, no pass;
+//   * NaN / +-inf anywhere, or log-weights without a finite maximum: the row goes to e_loo_rows_kernel through the device
+//     list (no host round trip), which follows the reference's NaN rules literally.
+// exp_tab (|error| <= 2 ulp) stands in for the libm exponential of the general kernel; arguments are clamped at -700, where a
+// weight is 1e-304 of the largest one.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Top2 {  // the two largest values a lane has seen (NEG: the two smallest, stored negated)
+  double a, b;
+  __device__ __forceinline__ void init() { a = -pinf(); b = -pinf(); }
+  __device__ __forceinline__ void put(double v) {
+    b = fmax(b, fmin(a, v));
+    a = fmax(a, v);
+  }
+  __device__ __forceinline__ void scale(double f) { a *= f; b *= f; }
+  // across the wave: largest and runner-up of the union (ties count: two lanes holding the maximum make them equal)
+  __device__ __forceinline__ void merge(int lane, double& m1, double& m2) const {
+    m1 = wave_all<R_MAX>(a);
+    const unsigned long long who = __ballot(a == m1);
+    const int src = __ffsll((long long)who) - 1;
+    m2 = wave_all<R_MAX>(lane == src ? b : a);
+  }
+};
+
+template <typename T, bool OWN>
+__global__ __launch_bounds__(256) void e_loo_wave_kernel(ELooParams P) {
+  __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int kW = 4;  // waves per workgroup
+  const int tid = threadIdx.x;
+  for (int j = tid; j < kTabN; j += kWave * kW) exp_table_entry(tab, j);
+  __syncthreads();
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const int lane = tid & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int S = __builtin_amdgcn_readfirstlane(P.n_draws);
+  const int n_tail = S < P.tail_len ? S : P.tail_len;
+  const int steps = (S + kWave * VEC - 1) / (kWave * VEC);
+  const double INF = pinf();
+  const auto unpack = [](const v4i& t, double (&o)[VEC]) {
+    if constexpr (VEC == 2) {
+      o[0] = __hiloint2double(t[1], t[0]);
+      o[1] = __hiloint2double(t[3], t[2]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (double)__int_as_float(t[e]);
     }
+  };
+  const int64_t w0 = (int64_t)blockIdx.x * kW + wv, nw = (int64_t)gridDim.x * kW;
+  for (int64_t r = w0; r < P.n_obs; r += nw) {
+    const T* xr = reinterpret_cast<const T*>(P.x) + r * P.stride_obs;
+    const T* wr = reinterpret_cast<const T*>(P.lw) + r * P.stride_obs;
+    const T* rr = reinterpret_cast<const T*>(P.lr) + r * P.stride_obs;
+    const int bytes = S * (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xr), 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wr), 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(rr), 0, bytes, 0x00020000);
+    const auto load3 = [&](int st, v4i& tx, v4i& tw, v4i& tl) {
+      const int off = (st * kWave + lane) * 16;  // (past the end: zeros)
+      tx = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+      tw = __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0);
+      if constexpr (OWN) tl = __builtin_amdgcn_raw_buffer_load_b128(rl, off, 0, 0);
+    };
+    v4i cx, cw, cl = {0, 0, 0, 0}, nx = {0, 0, 0, 0}, nwv = {0, 0, 0, 0}, nl = {0, 0, 0, 0};
+    load3(0, cx, cw, cl);
+    if (steps > 1) load3(1, nx, nwv, nl);
+    const double x0 = uniform_d((double)xr[0]), q0 = x0 * x0;
+    // ---- first vector: the starting maxima (wave-uniform) and the lanes' first values ------------------------------
+    double fx[VEC], fw[VEC], fl[VEC];
+    unpack(cx, fx);
+    unpack(cw, fw);
+    if constexpr (OWN) unpack(cl, fl);
+    double m, mr;
+    {
+      double am = -INF, bm = -INF;  // (the first vector is complete in every lane: S >= 64 VEC)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        am = fmax(am, fw[e]);
+        if constexpr (OWN) bm = fmax(bm, fl[e]);
+      }
+      if constexpr (OWN) wave_all2<R_MAX>(am, bm, m, mr);
+      else m = mr = wave_all<R_MAX>(am);
+    }
+    bool bad = !(m > -INF && m < INF) || !(mr > -INF && mr < INF);  // nothing finite to start from (or a NaN / +inf): general kernel
+    double sa = 0.0, sb = 0.0, sc = 0.0, sd = 0.0;
+    Top2 tb, h1lo, h1hi, h2lo, h2hi;  // largest log ratio; -smallest / largest x r; -smallest / largest x^2 r
+    tb.init(); h1lo.init(); h1hi.init(); h2lo.init(); h2hi.init();
+    double xlo = fx[0], xhi = fx[0], qlo = fx[0] * fx[0], qhi = qlo;
+    bool three_x = false, three_q = false;
+    double xdev = 0.0, qdev = 0.0;
+    const auto elem = [&](double x, double a, double b, bool valid) {
+      if (!valid) {  // past the end of the row: a draw that changes nothing
+        x = xlo;
+        a = -INF;
+        b = -INF;
+      }
+      const double q = valid ? x * x : qlo;
+      bad |= !(q < INF) | (a != a) | (b != b);
+      if (__ballot(a > m) != 0ull) {  // a larger log-weight: bring the sums to the new maximum
+        const double mn = wave_all<R_MAX>(fmax(a, m));
+        const double f = exp_tab(fmax(m - mn, -700.0), tab);
+        sa *= f; sb *= f; sc *= f; sd *= f * f;
+        if constexpr (!OWN) {
+          h1lo.scale(f); h1hi.scale(f); h2lo.scale(f); h2hi.scale(f);
+          mr = mn;
+        }
+        m = mn;
+      }
+      const double w = valid ? exp_tab(fmax(a - m, -700.0), tab) : 0.0;
+      sa += w;
+      sb = fma(w, x, sb);
+      sc = fma(w, q, sc);
+      sd = fma(w, w, sd);
+      double rv = w;
+      if constexpr (OWN) {
+        if (__ballot(b > mr) != 0ull) {
+          const double mn = wave_all<R_MAX>(fmax(b, mr));
+          const double f = exp_tab(fmax(mr - mn, -700.0), tab);
+          h1lo.scale(f); h1hi.scale(f); h2lo.scale(f); h2hi.scale(f);
+          mr = mn;
+        }
+        rv = exp_tab(fmax(b - mr, -700.0), tab);
+      }
+      const double lb = OWN ? b : a;
+      tb.put(valid ? lb : -INF);
+      const double h1 = x * rv, h2 = q * rv;
+      h1lo.put(valid ? -h1 : -INF);
+      h1hi.put(valid ? h1 : -INF);
+      h2lo.put(valid ? -h2 : -INF);
+      h2hi.put(valid ? h2 : -INF);
+      // distinct values of x and x^2 in this lane: a third one shows as a value strictly inside [lo, hi], or outside it
+      // when lo and hi already differ
+      {
+        const bool out = (x < xlo) | (x > xhi), in = (x != xlo) & (x != xhi);
+        three_x |= in & (!out | (xlo != xhi));
+        xlo = fmin(xlo, x);
+        xhi = fmax(xhi, x);
+        const bool outq = (q < qlo) | (q > qhi), inq = (q != qlo) & (q != qhi);
+        three_q |= inq & (!outq | (qlo != qhi));
+        qlo = fmin(qlo, q);
+        qhi = fmax(qhi, q);
+      }
+      xdev = fmax(xdev, fabs(x - x0));
+      qdev = fmax(qdev, fabs(q - q0));
+    };
+#pragma unroll 1
+    for (int st = 0; st < steps; ++st) {
+      double vx[VEC], vw[VEC], vl[VEC];
+      unpack(cx, vx);
+      unpack(cw, vw);
+      if constexpr (OWN) unpack(cl, vl);
+      cx = nx; cw = nwv; cl = nl;
+      if (st + 2 < steps) load3(st + 2, nx, nwv, nl);
+      const bool valid = (st * kWave + lane) * VEC < S;  // (S is a multiple of VEC: a vector is inside the row or past it)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) elem(vx[e], vw[e], OWN ? vl[e] : vw[e], valid);
+    }
+    // ---- across the lanes ----------------------------------------------------------------------------------------
+    double SA, SB, SC, SD;
+    wave_all4<R_SUM>(sa, sb, sc, sd, SA, SB, SC, SD);
+    double xmn, xmx, qmn, qmx, nxmn, nqmn;
+    wave_all4<R_MAX>(-xlo, xhi, -qlo, qhi, nxmn, xmx, nqmn, qmx);
+    xmn = -nxmn; qmn = -nqmn;
+    double XD, QD;
+    wave_all2<R_MAX>(xdev, qdev, XD, QD);
+    const bool two_x = __ballot(three_x | ((xlo != xmn) & (xlo != xmx)) | ((xhi != xmn) & (xhi != xmx))) == 0ull;
+    const bool two_q = __ballot(three_q | ((qlo != qmn) & (qlo != qmx)) | ((qhi != qmn) & (qhi != qmx))) == 0ull;
+    double b1, b2, l1a, l1b, r1a, r1b, l2a, l2b, r2a, r2b;
+    tb.merge(lane, b1, b2);
+    h1lo.merge(lane, l1a, l1b);
+    h1hi.merge(lane, r1a, r1b);
+    h2lo.merge(lane, l2a, l2b);
+    h2hi.merge(lane, r2a, r2b);
+    const double h1mn = -l1a, h1mx = r1a, h2mn = -l2a, h2mx = r2a;
+    bad |= !(m < INF) | !(mr < INF);
+    const bool defer = __ballot(bad) != 0ull;
+    if (defer) {
+      if (lane == 0) {
+        const unsigned long long idx = atomicAdd(P.slow_count, 1ull);
+        P.slow_list[idx] = (unsigned)r;
+      }
+      continue;
+    }
+    // ---- is any of the five counts needed?  (1 % of slack: a runner-up right at the tolerance is counted, not guessed) ----
+    const auto near = [](double runner, double ext) { return fabs(runner - ext) <= 1.01 * (kCloseAtol + kCloseRtol * fabs(ext)); };
+    const double rv2 = exp(b2 - b1);  // the runner-up among the ratios (the largest is 1)
+    double n_close_r = 1.0, c1l = 1.0, c1r = 1.0, c2l = 1.0, c2r = 1.0;
+    if (near(rv2, 1.0) || near(-l1b, h1mn) || near(r1b, h1mx) || near(-l2b, h2mn) || near(r2b, h2mx)) {
+      double cr = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
+      const double t1l = kCloseAtol + kCloseRtol * fabs(h1mn), t1r = kCloseAtol + kCloseRtol * fabs(h1mx);
+      const double t2l = kCloseAtol + kCloseRtol * fabs(h2mn), t2r = kCloseAtol + kCloseRtol * fabs(h2mx);
+#pragma unroll 1
+      for (int st = 0; st < steps; ++st) {
+        v4i tx, tw, tl = {0, 0, 0, 0};
+        load3(st, tx, tw, tl);
+        double vx[VEC], vl[VEC];
+        unpack(tx, vx);
+        unpack(OWN ? tl : tw, vl);
+        if ((st * kWave + lane) * VEC < S) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const double rv = exp_tab(fmax(vl[e] - mr, -700.0), tab);
+            const double h1 = vx[e] * rv, h2 = (vx[e] * vx[e]) * rv;
+            cr += (fabs(rv - 1.0) <= kCloseAtol + kCloseRtol) ? 1.0 : 0.0;
+            a1 += (fabs(h1 - h1mn) <= t1l) ? 1.0 : 0.0;
+            a2 += (fabs(h1 - h1mx) <= t1r) ? 1.0 : 0.0;
+            a3 += (fabs(h2 - h2mn) <= t2l) ? 1.0 : 0.0;
+            a4 += (fabs(h2 - h2mx) <= t2r) ? 1.0 : 0.0;
+          }
+        }
+      }
+      wave_all4<R_SUM>(a1, a2, a3, a4, c1l, c1r, c2l, c2r);
+      n_close_r = wave_all<R_SUM>(cr);
+    }
+    if (lane == 0)
+      e_loo_finish(P, r, n_tail, 0u, SA, SB, SC, SD, x0, q0, XD, QD, xmn, xmx, qmn, qmx, two_x, two_q, (double)S, n_close_r, c1l, c1r,
+                   c2l, c2r);
   }
 }
 

@@ -69,6 +69,7 @@ hipError_t launch_waic(const void* in, const int64_t* row_index, int dtype, int6
 // weighted expectations + function-specific Pareto k (e_loo.py:56-264): x, lw, lr share dtype, shape and strides; lr may equal lw
 hipError_t launch_e_loo(const void* x, const void* lw, const void* lr, int dtype, int64_t n_obs, int n_draws, int64_t stride_obs,
                         int64_t stride_draw, int tail_len, double* mean, double* var, double* k_mean, double* k_var, double* k_none,
+                        unsigned* slow_list, unsigned long long* slow_count,
                         hipStream_t stream);
 // weighted quantiles of e_loo (e_loo.py:468-515, 534-554): out[n_obs][n_probs]; probs is a DEVICE pointer
 hipError_t launch_e_loo_quantiles(const void* x, const void* lw, int dtype, int64_t n_obs, int n_draws, int64_t stride_obs,

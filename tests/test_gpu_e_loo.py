@@ -124,3 +124,45 @@ def test_device_tensors_and_front(eng):
     same(np.asarray(rq.pareto_k).ravel(), wq["k_none"], 1e-14, "pareto_k of the quantile type")
     with pytest.raises(ValueError):
         pl.compute_pareto_k(x, lr, tail_len=4)
+
+
+@pytest.mark.parametrize("S,dt", [(2000, np.float64), (4000, np.float32), (130, np.float64)])
+def test_one_pass_kernel_special_rows(eng, S, dt):
+    """Rows that steer the one-pass wave kernel (pla_eloo.h) through its branches: counts needed (ties at the extremes,
+    constant weights, a heap of x r below the absolute tolerance), two- and three-valued draws, rows it must hand to the
+    general kernel (NaN / inf), zero weights (-inf), the largest log-weight late in the row."""
+    rng = np.random.default_rng(S)
+    N = 24
+    lr = (rng.uniform(0.1, 0.9, size=(N, 1)) * rng.exponential(size=(N, S)))
+    x = rng.normal(size=(N, S)) * 2.0 + 0.3
+    x[0] = rng.integers(0, 2, size=S)                    # two-valued draws (a 0/1 prediction)
+    x[1] = rng.integers(0, 3, size=S)                    # three values
+    lr[2] = 0.25                                         # constant ratios: every r is allclose to the largest
+    lr[3] *= 60.0                                        # wide range: most x r fall below atol of the smallest
+    lr[4, 7] = lr[4, S - 3] = lr[4].max() + 1.0          # the two largest ratios tie
+    lr[5, : S // 2] = -np.inf                            # zero weights
+    x[6, 11] = np.inf
+    lr[7, S // 3] = np.nan
+    x[8] = np.abs(x[8]) + 0.5                            # positive draws
+    x[9] = -np.abs(x[9]) - 0.5                           # negative draws
+    lr[10, S - 1] = lr[10].max() + 30.0                  # the maximum arrives last
+    x[11] = 3.25                                         # constant draws
+    x[12, ::2], x[12, 1::2] = 1.0, -1.0                  # x two-valued, x^2 constant
+    x[13] = np.round(x[13], 1)                           # many ties among the draws
+    x[14, S - 1] = np.nan
+    lr[15] = -np.inf                                     # nothing finite
+    x, lr = x.astype(dt), lr.astype(dt)
+    lw = lr.copy()
+    want = orc.e_loo_arrays(x.astype(np.float64), lw.astype(np.float64), lr.astype(np.float64))
+    for ratios in (lr, None):
+        res = eng.e_loo(x, lw, ratios)
+        same(res["mean"], want["mean"], 1e-9, "mean")
+        same(res["var"], want["var"], 1e-8, "variance")
+        for key in ("k_mean", "k_var", "k_none"):
+            same(res[key], want[key], 1e-14, key)
+    lw2 = lw + rng.normal(size=(N, 1)).astype(dt)         # weights that are not the ratios (any normalisation)
+    want2 = orc.e_loo_arrays(x.astype(np.float64), lw2.astype(np.float64), lr.astype(np.float64))
+    res2 = eng.e_loo(x, lw2, lr)
+    same(res2["mean"], want2["mean"], 1e-9, "mean (own ratios)")
+    for key in ("k_mean", "k_var", "k_none"):
+        same(res2[key], want2[key], 1e-14, key + " (own ratios)")
