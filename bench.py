@@ -28,18 +28,21 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
 def measured_traffic(n_obs, n_draws, dtype):
-    """HBM bytes per LOO pass (wave kernel + fit kernel + general kernel) from the rocprofv3 PMC passes (tools/profile.sh ->
-    profiles/traffic_latest.json: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), or None
-    when no profile of this exact workload is committed."""
-    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        if t.get("obs") == n_obs and t.get("draws") == n_draws and t.get("dtype") == dtype:
-            return t["hbm_read_bytes"] + t["hbm_write_bytes"]
-    except Exception:
-        pass
-    return None
+    """(HBM bytes per LOO pass, file) from the committed rocprofv3 PMC passes of this exact workload (tools/profile.sh ->
+    profiles/*traffic*.json: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE, summed over the kernels of the pass),
+    or (None, None) when there is none."""
+    import glob
+
+    first = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    for path in [first] + sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            if t.get("obs") == n_obs and t.get("draws") == n_draws and t.get("dtype") == dtype:
+                return t["hbm_read_bytes"] + t["hbm_write_bytes"], os.path.relpath(path, ROOT)
+        except Exception:
+            pass
+    return None, None
 
 
 def launch_ranks(n):
@@ -171,6 +174,7 @@ def main():
             dist.destroy_process_group()
         return
 
+    traffic, traffic_file = measured_traffic(n_local, S, args.dtype)
     out = {
         "metric": "psis_loo_observations_per_second",
         "value": world * n_local * args.steps / elapsed,
@@ -201,9 +205,9 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": measured_traffic(n_local, S, args.dtype),
-            "traffic_source": "profiles/traffic_latest.json (builder's rocprofv3 --pmc passes of this workload, replayed; not "
-                              "counted in this run)",
+            "traffic": traffic,
+            "traffic_source": (f"{traffic_file} (builder's rocprofv3 --pmc passes of this workload, replayed; not counted in "
+                               "this run)") if traffic_file else None,
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes,
             "kernels": "whole pass: wave_loo_kernel (statistics, sweep, tail selection) + fit_rows_kernel (GPD fit, smoothing, "

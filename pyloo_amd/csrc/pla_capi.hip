@@ -436,7 +436,11 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
   const bool ingest = obs_fastest_device(mem_space, row_index, n_src, n_draws, stride_obs, stride_draw);
   // observations-fastest PSIS-LOO: the lane-per-observation kernels read the matrix as it lies (pla_col.h); PLA_INGEST_TRANSPOSE=1
   // keeps round 1's transposing ingestion (A/B runs), which also serves the shapes the column kernels do not take
-  constexpr int64_t kColBlock = 262144;  // observations per launch: 2 GB of candidate lists
+  static const int64_t kColBlock = [] {  // observations per launch: 8 KB of candidate lists each (PLA_COL_BLOCK: A/B runs)
+    const char* e = getenv("PLA_COL_BLOCK");
+    const int64_t v = e ? atoll(e) : 0;
+    return v >= 256 ? v : (int64_t)262144;
+  }();
   int col_kq = 0;
   static const bool force_transpose = getenv("PLA_INGEST_TRANSPOSE") && atoi(getenv("PLA_INGEST_TRANSPOSE")) != 0;
   const bool use_col = ingest && method == PLA_PSIS && !force_transpose && pla::col_supported((int)n_draws, (int)tail_count, &col_kq);

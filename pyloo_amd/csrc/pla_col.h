@@ -47,6 +47,12 @@ constexpr int kColFlush = PLA_COL_FLUSH;
 constexpr int kColRing = 2 * kColFlush;  // staging ring per lane (at most kColFlush - 1 + 4 entries wait between two checks)
 constexpr int kColSample = 512;   // draws in the pre-pass: 64 groups of 8
 constexpr int kColCap = 1024;     // candidate list capacity per observation (doubles)
+// Layout of the lists: 64 consecutive observations (the lanes of one sweep wave) share a 512 KB group, interleaved burst by
+// burst -- entry j of observation 64 g + l lies at double  g * 65536 + ((j / 8) * 64 + l) * 8 + j % 8.  The 64-byte bursts
+// the lanes of a wave write at about the same time are then neighbours (a few 4 KB pages per store instruction instead of
+// 64 pages 8 KB apart: address translation and DRAM page locality), at the price of a strided read in the selection.
+__device__ __forceinline__ int64_t col_list_base(int64_t obs) { return (obs >> 6) * (int64_t)(64 * kColCap) + (obs & 63) * 8; }
+__device__ __forceinline__ int col_list_entry(int j) { return (j >> 3) * 512 + (j & 7); }
 
 struct ColParams {
   const void* in;      // element (observation i, draw s) at in[s * ld + i]
@@ -135,8 +141,9 @@ __global__ __launch_bounds__(256, PLA_COL_WAVES) void col_sweep_kernel(ColParams
   double* const mine = stage[threadIdx.x];
   // (the lists of this launch's observations: at most 262 144 x 8 KB = 2 GB, inside one descriptor's 32-bit range)
   const __amdgpu_buffer_rsrc_t rs_list = __builtin_amdgcn_make_buffer_rsrc(
-      P.cand, 0, (int)(unsigned)(((P.n_obs * (int64_t)kColCap * 8) > 0xfffffff0ll) ? 0xfffffff0ll : P.n_obs * (int64_t)kColCap * 8), 0x00020000);
-  const int list_off = (int)((live ? i : 0) * (int64_t)kColCap * 8);
+      P.cand, 0, (int)(unsigned)(((((P.n_obs + 63) & ~63ll) * (int64_t)kColCap * 8) > 0xfffffff0ll) ? 0xfffffff0ll : ((P.n_obs + 63) & ~63ll) * (int64_t)kColCap * 8), 0x00020000);
+  static_assert(kColFlush == 8, "a flush is one 64-byte burst of the interleaved list layout");
+  const int list_off = (int)(col_list_base(live ? i : 0) * 8);
   const char* tabc = reinterpret_cast<const char*>(tab);
   constexpr int U = PLA_COL_U;
   int c4096 = 4096, cm4096 = -4096, four = 4;
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256, PLA_COL_WAVES) void col_sweep_kernel(ColParams
   const auto flush4 = [&]() {
     const bool go = cnt - flushed >= kColFlush;
     const bool wr = go & (flushed + kColFlush <= kColCap) & live;  // (bitwise: no short-circuit branches inside the sweep)
-    const int off = wr ? list_off + 8 * flushed : (int)0xffffff00;
+    const int off = wr ? list_off + 512 * flushed : (int)0xffffff00;  // burst flushed / 8, 4 KB apart
     const double* src = &mine[flushed & (kColRing - 1)];  // (flushed is a multiple of kColFlush: no wrap inside a burst)
 #pragma unroll
     for (int q = 0; q < kColFlush / 2; ++q)
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(256, PLA_COL_WAVES) void col_sweep_kernel(ColParams
   }
   flush4();
   for (int j = flushed; j < cnt && j < kColCap; ++j)  // the last, fewer than a burst, one by one
-    if (live) P.cand[i * (int64_t)kColCap + j] = mine[j & (kColRing - 1)];
+    if (live) P.cand[col_list_base(i) + col_list_entry(j)] = mine[j & (kColRing - 1)];
   if (live) {
     double* o = P.scal + i * 8;
     o[0] = mp; o[1] = -nmn; o[2] = -nmx; o[3] = s1; o[4] = s2; o[5] = (double)cnt; o[6] = t_raw;
@@ -238,7 +245,7 @@ struct CandInList {  // x = raw - max raw with the reference's single rounding (
   const double* list;
   double m;
   SM& sm;
-  __device__ __forceinline__ double at(unsigned c) const { return (-list[c]) - m; }
+  __device__ __forceinline__ double at(unsigned c) const { return (-list[col_list_entry((int)c)]) - m; }
   __device__ __forceinline__ unsigned* dump_bin(int lane) const { return &sm.dump_bin[lane]; }
   __device__ __forceinline__ double* dump_slot(int lane) const { return &sm.dump_slot[lane]; }
 };
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(kWave * 4) void col_select_kernel(ColParams P, Fast
       // the sums about the true shift: e^x = e^x' e^-(m - m'), e^-x = e^-x' e^(m - m')   (R < 690 keeps both finite)
       const double s1 = lane == 0 ? s1p * exp_tab(-delta, tb.tab) : 0.0;
       const double s2 = lane == 0 ? s2p * exp_tab(delta, tb.tab) : 0.0;
-      const CandInList<SM> src{P.cand + r * (int64_t)kColCap, m, sm};
+      const CandInList<SM> src{P.cand + col_list_base(r), m, sm};
       wave_sync();
       wave_select_split<SM, TB, (CAP::kMaxTail + 63) / 64, CandInList<SM>>(F, sm, tb, r, lane, M, m, mn, s1, s2, (unsigned)ncand, k1, sh,
                                                                            magic, c256, slow, src);

@@ -557,7 +557,7 @@ bool col_supported(int n_draws, int tail_count, int* kq) {
   *kq = k;
   return true;
 }
-size_t col_workspace_bytes(int64_t n_obs) { return (size_t)n_obs * (kColCap + 8) * sizeof(double); }
+size_t col_workspace_bytes(int64_t n_obs) { return (size_t)((n_obs + 63) & ~63ll) * (kColCap + 8) * sizeof(double); }  // (lists in groups of 64)
 
 hipError_t launch_col(const RowsParams& p, int dtype, int kq, void* col_ws, hipStream_t stream) {
   if (p.n_obs <= 0) return hipSuccess;
@@ -567,7 +567,7 @@ hipError_t launch_col(const RowsParams& p, int dtype, int kq, void* col_ws, hipS
   while (root_ * root_ > p.tail_count) --root_;
   while ((root_ + 1) * (root_ + 1) <= p.tail_count) ++root_;
   const int mestM = 30 + root_;
-  ColParams c{p.in, p.n_obs, p.n_draws, p.stride_draw, kq, (double*)col_ws, (double*)col_ws + (size_t)p.n_obs * kColCap};
+  ColParams c{p.in, p.n_obs, p.n_draws, p.stride_draw, kq, (double*)col_ws, (double*)col_ws + (size_t)((p.n_obs + 63) & ~63ll) * kColCap};
   const unsigned g1 = (unsigned)((p.n_obs + 255) / 256);
   if (dtype == PLA_F64) hipLaunchKernelGGL(col_sweep_kernel<double>, dim3(g1), dim3(256), 0, stream, c);
   else hipLaunchKernelGGL(col_sweep_kernel<float>, dim3(g1), dim3(256), 0, stream, c);
