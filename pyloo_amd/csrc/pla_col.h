@@ -43,8 +43,12 @@ namespace pla {
 #ifndef PLA_COL_FLUSH
 #define PLA_COL_FLUSH 8       // candidates per store burst: 8 x 8 bytes = half a cache line
 #endif
+#ifndef PLA_COL_CHECK
+#define PLA_COL_CHECK 8  // draws between two looks at the staging ring (a flush is four store instructions whether or not a lane has a burst ready)
+#endif
 constexpr int kColFlush = PLA_COL_FLUSH;
-constexpr int kColRing = 2 * kColFlush;  // staging ring per lane (at most kColFlush - 1 + 4 entries wait between two checks)
+static_assert(PLA_COL_FLUSH - 1 + PLA_COL_CHECK <= 2 * PLA_COL_FLUSH, "the ring must hold what arrives between two checks");
+constexpr int kColRing = 2 * kColFlush;  // staging ring per lane (at most kColFlush - 1 + PLA_COL_CHECK entries wait between two checks)
 constexpr int kColSample = 512;   // draws in the pre-pass: 64 groups of 8
 constexpr int kColCap = 1024;     // candidate list capacity per observation (doubles)
 // Layout of the lists: 64 consecutive observations (the lanes of one sweep wave) share a 512 KB group, interleaved burst by
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(256, PLA_COL_WAVES) void col_sweep_kernel(ColParams
     mine[cand ? (cnt & (kColRing - 1)) : kColRing] = ll;
     cnt += cand ? 1 : 0;
   };
-  // kColFlush staged candidates -> the observation's list, when there are that many (called every fourth draw: at most four
+  // kColFlush staged candidates -> the observation's list, when there are that many (called every PLA_COL_CHECK-th draw: at most that many
   // arrive in between, so the ring never overflows).  Bounds-checked buffer stores: what must not be written -- nothing to
   // flush yet, list full, idle lane -- gets an offset past the end of the descriptor, which the hardware drops.
   typedef int v4i __attribute__((ext_vector_type(4)));
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(256, PLA_COL_WAVES) void col_sweep_kernel(ColParams
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       one((double)src[u]);
-      if (u % 4 == 3) flush4();
+      if (u % PLA_COL_CHECK == PLA_COL_CHECK - 1) flush4();
       // (a few draws interleave -- the table read of one under the arithmetic of the others -- but not all sixteen: the
       // scheduler would otherwise start every draw of the batch at once and spill)
       if (u % PLA_COL_ILP == PLA_COL_ILP - 1) __builtin_amdgcn_sched_barrier(0);
