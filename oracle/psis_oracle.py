@@ -379,6 +379,55 @@ def e_loo_arrays(x, log_weights, log_ratios=None, probs=None):
     return out
 
 
+
+# ---- loo_predictive_metric / loo_score: the closed forms around psislw + e_loo ----------------------------------------
+def predictive_metric(y, yhat, metric):
+    """{"estimate", "se"} of one metric (pyloo loo_predictive_metric.py:234-356)."""
+    y, yhat = np.asarray(y, dtype=np.float64), np.asarray(yhat, dtype=np.float64)
+    n = len(y)
+    if metric in ("mae", "mse", "rmse"):
+        e = np.abs(y - yhat) if metric == "mae" else (y - yhat) ** 2      # 247-250, 268-271
+        est, se = np.mean(e), np.std(e, ddof=1) / np.sqrt(n)
+        if metric == "rmse":                                               # 291-298: first-order Taylor expansion
+            return {"estimate": np.sqrt(est), "se": np.sqrt(se**2 / est / 4)}
+        return {"estimate": est, "se": se}
+    hit = (yhat > 0.5).astype(int) == y                                    # 319-320, 348
+    if metric == "acc":
+        est = np.mean(hit.astype(int))
+        return {"estimate": est, "se": np.sqrt(est * (1 - est) / n)}       # 321-326
+    neg = y == 0                                                           # 349-356
+    tn, tp = np.mean(hit[neg]), np.mean(hit[~neg])
+    return {"estimate": (tp + tn) / 2, "se": np.sqrt((tp * (1 - tp) + tn * (1 - tn)) / 4 / n)}
+
+
+def loo_predictive_metric_arrays(x, ll, y, metric="mae", reff=1.0):
+    """loo_predictive_metric.py:208-231 on (n_obs, n_draws) arrays: psislw(-ll), weighted mean of x, the metric."""
+    lw, _ = psislw(-ll, reff)
+    pred = e_loo_arrays(x, lw, -ll)["mean"]
+    return predictive_metric(y, pred, metric)
+
+
+def crps(exx, exy, scale=False):
+    """loo_score.py:326-346."""
+    return -exy / exx - 0.5 * np.log(exx) if scale else 0.5 * exx - exy
+
+
+def loo_score_arrays(x, x2, y, ll, reff=1.0, permutations=1, scale=False):
+    """Pointwise LOO-CRPS / SCRPS on (n_obs, n_draws) arrays (loo_score.py:219-239, 277-323); draws the pairings from
+    NumPy's global generator like the reference (305)."""
+    s = x.shape[-1]
+    exx = 0.0
+    for _ in range(permutations):
+        shuffle = np.random.permutation(s)
+        joint = -ll - ll[:, shuffle]
+        lw, _ = psislw(joint, reff)
+        exx = exx + e_loo_arrays(np.abs(x - x2[:, shuffle]), lw, joint)["mean"]
+    exx = exx / permutations
+    lw, k = psislw(-ll, reff)
+    exy = e_loo_arrays(np.abs(x - np.asarray(y).reshape(-1, 1)), lw, -ll)["mean"]
+    return crps(exx, exy, scale), k
+
+
 # ---------------------------------------------------------------------------------------------
 # Vectorised NumPy backend (SURVEY section 8d: the second CPU line of the bench).  Same arithmetic as
 # ``loo_pointwise`` with the per-observation Python loop replaced by whole-matrix NumPy calls; rows

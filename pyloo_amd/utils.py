@@ -30,14 +30,36 @@ class LogLikelihoodArray:
 
 
 class SimpleInferenceData:
-    """Duck-typed InferenceData used only when ArviZ is not installed: ``.log_likelihood`` is a
-    mapping var_name -> LogLikelihoodArray; ``.posterior`` is a mapping var_name -> ndarray."""
+    """Duck-typed InferenceData used only when ArviZ is not installed: ``.log_likelihood`` (and any other sample group, e.g.
+    ``posterior_predictive``) is a mapping var_name -> LogLikelihoodArray ``(chain, draw, *obs)``; ``.posterior`` and
+    ``.observed_data`` are mappings var_name -> ndarray."""
 
-    def __init__(self, log_likelihood=None, posterior=None):
+    def __init__(self, log_likelihood=None, posterior=None, observed_data=None, **sample_groups):
         if log_likelihood is not None:
             self.log_likelihood = {k: LogLikelihoodArray(v, k) for k, v in log_likelihood.items()}
         if posterior is not None:
             self.posterior = {k: np.asarray(v) for k, v in posterior.items()}
+        if observed_data is not None:
+            self.observed_data = {k: np.asarray(v) for k, v in observed_data.items()}
+        for group, content in sample_groups.items():
+            if content is not None:
+                setattr(self, group, {k: LogLikelihoodArray(v, k) for k, v in content.items()})
+
+
+def group_variable(idata, group, var_name, arg="var_name"):
+    """One variable of one group, with the reference's error texts (e_loo.py:170-196, loo_score.py:456-515,
+    loo_predictive_metric.py:156-178)."""
+    if not hasattr(idata, group):
+        raise ValueError(f"InferenceData object does not have a {group} group")
+    content = getattr(idata, group)
+    names = list(content.data_vars) if hasattr(content, "data_vars") else list(content.keys())
+    if var_name is None:
+        if len(names) == 1:
+            return content[names[0]], names[0]
+        raise ValueError(f"Multiple variables found in {group} group. Please specify {arg} from: {names}")
+    if var_name not in names:
+        raise ValueError(f"Variable '{var_name}' not found in {group} group. Available variables: {names}")
+    return content[var_name], var_name
 
 
 def to_inference_data(obj):
@@ -54,7 +76,7 @@ def to_inference_data(obj):
     if isinstance(obj, SimpleInferenceData) or hasattr(obj, "log_likelihood") or hasattr(obj, "posterior"):
         return obj
     if isinstance(obj, dict):
-        return SimpleInferenceData(log_likelihood=obj.get("log_likelihood"), posterior=obj.get("posterior"))
+        return SimpleInferenceData(**obj)
     arr = np.asarray(obj)
     if arr.dtype.kind in "fiu" and arr.ndim >= 3:
         return SimpleInferenceData(log_likelihood={"obs": arr})

@@ -61,3 +61,11 @@ class OracleEngine:
                     lw[i], diag[i] = orc.psis_row(logw[i], tail_count)
                 return lw, diag
             return orc.importance_weights(logw, method)
+
+    def e_loo(self, x, log_weights, log_ratios=None, tail_len=20):
+        x, lw = np.asarray(x, dtype=np.float64), np.asarray(log_weights, dtype=np.float64)
+        lr = None if log_ratios is None else np.asarray(log_ratios, dtype=np.float64)
+        with np.errstate(all="ignore"):
+            r = orc.e_loo_arrays(x, lw, lr)
+        return {k: r[k] for k in ("mean", "var", "k_mean", "k_var", "k_none")}
+
