@@ -11,6 +11,7 @@ STEPS=${STEPS:-5}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
+rm -rf $OUT/trace $OUT/fetch $OUT/write   # (a previous run of another workload must not leak into this summary)
 cd /tmp && export TMPDIR=/tmp
 ARGS="$ROOT/bench.py --obs $OBS --steps $STEPS --warmup 2 --no-cpu"
 # CONFIG=C5 (etc.): a BASELINE preset instead of --obs (its shapes come from bench.py)
@@ -39,7 +40,7 @@ trace = collections.defaultdict(list)
 for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         trace[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
-lines = ["# rocprofv3 summary ($TAG): bench.py ${CONFIG:+--config $CONFIG }--obs %d --steps $STEPS --warmup 2" % obs, "",
+lines = ["# rocprofv3 summary ($TAG): " + ("bench.py --config $CONFIG" if "$CONFIG" else "bench.py --obs %d" % obs) + " --steps $STEPS --warmup 2 --no-cpu", "",
          "| kernel | calls | avg ms (all launches) | avg ms (last $STEPS = timed) | total ms | % |", "|---|---|---|---|---|---|"]
 summary = {"obs": obs, "kernels": {}}
 for name, r in sorted(stats.items(), key=lambda kv: -float(kv[1]["TotalDurationNs"])):
@@ -64,7 +65,13 @@ if main:
     # times the whole pass, so the traffic is summed over its kernels too
     per = {k: {"hbm_read_bytes": summary["kernels"][k]["hbm_read_bytes"], "hbm_write_bytes": summary["kernels"][k]["hbm_write_bytes"],
                "avg_ms_timed": summary["kernels"][k].get("avg_ms_timed")} for k in main}
-    json.dump({"obs": obs, "draws": int("${DRAWS:-4000}"), "dtype": "${DTYPE:-f64}", "kernels": per,
+    # the workload as bench.py itself reports it (its JSON line in trace.log): a --config preset overrides --obs
+    shape = {"obs": obs, "draws": int("${DRAWS:-4000}"), "dtype": "${DTYPE:-f64}"}
+    for ln in open(out + "/trace.log"):
+        if ln.startswith("{") and '"metric"' in ln:
+            b = json.loads(ln)
+            shape = {"obs": b["config"]["obs_per_gpu"], "draws": b["config"]["draws"], "dtype": b["dtype"]}
+    json.dump({**shape, "kernels": per,
                "hbm_read_bytes": sum(v["hbm_read_bytes"] for v in per.values()),
                "hbm_write_bytes": sum(v["hbm_write_bytes"] for v in per.values()),
                "note": "FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B), WRITE_SIZE as is; summed over the kernels of one LOO pass"},
