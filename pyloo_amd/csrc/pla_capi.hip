@@ -443,6 +443,7 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
   }();
   int col_kq = 0;
   static const bool force_transpose = getenv("PLA_INGEST_TRANSPOSE") && atoi(getenv("PLA_INGEST_TRANSPOSE")) != 0;
+  constexpr int64_t kDevBlock = (int64_t)1 << 20;  // rows per launch of a device-resident matrix (bounds the hand-over buffer)
   const bool use_col = ingest && method == PLA_PSIS && !force_transpose && pla::col_supported((int)n_draws, (int)tail_count, &col_kq);
 
   pla::RowsParams p{};
@@ -465,13 +466,19 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
       // rows one launch processes (all of them on the device path, one staging chunk on the host path)
       if ((tail_count <= 250 && n_draws >= 256 && n_draws <= 4096) || (tail_count <= 448 && n_draws >= 256)) {  // (one-chunk / chunked wave kernels)
         const int64_t chunk_rows = use_col ? (n_obs < kColBlock ? n_obs : kColBlock) : staged_chunk_rows(mem_space, ingest, n_obs, n_draws, esz);
-        const int64_t rows = (mem_space == PLA_DEVICE && !ingest) ? n_obs : chunk_rows;
+        // (device-resident matrices run in blocks of kDevBlock rows, so the buffer is bounded: 1.7 GB at M = 190 however
+        // many observations there are)
+        const int64_t rows = (mem_space == PLA_DEVICE && !ingest) ? (n_obs < kDevBlock ? n_obs : kDevBlock) : chunk_rows;
         const int stride = (int)((tail_count + 63) & ~(int64_t)63);  // 16 lanes x 4 values per quad
         rc = grow(&eng->d_ws, &eng->d_ws_bytes, (size_t)rows * (size_t)(stride + 8) * sizeof(double));
-        if (rc) return rc;
-        p.ws_y = (double*)eng->d_ws;
-        p.ws_s = (double*)eng->d_ws + (size_t)rows * stride;
-        p.ws_stride = stride;
+        if (rc == PLA_ERR_NOMEM && !use_col) {
+          rc = 0;  // no room for the hand-over: the fused kernels need none (the split pass is the faster, not the only, path)
+        } else {
+          if (rc) return rc;
+          p.ws_y = (double*)eng->d_ws;
+          p.ws_s = (double*)eng->d_ws + (size_t)rows * stride;
+          p.ws_stride = stride;
+        }
       }
     }
   }
@@ -542,10 +549,15 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
       rc = device_rows(eng, row_index, n_obs, n_src, s, &p.row_index);
       if (rc) return rc;
     }
-    p.diag = dd;
-    p.loo_i = dl;
-    p.lppd_i = dp;
-    {
+    const int64_t* all_rows = p.row_index;
+    for (int64_t r0 = 0; r0 < n_obs; r0 += kDevBlock) {
+      const int64_t nr = (n_obs - r0 < kDevBlock) ? (n_obs - r0) : kDevBlock;
+      p.n_obs = nr;
+      if (all_rows) p.row_index = all_rows + r0;
+      else p.in = (const char*)ll + (size_t)r0 * (size_t)stride_obs * esz;
+      p.diag = dd ? dd + r0 : nullptr;
+      p.loo_i = dl ? dl + r0 : nullptr;
+      p.lppd_i = dp ? dp + r0 : nullptr;
       TimedLaunch t(eng, s);
       PLA_HIP(pla::launch_rows(p, dtype, false, s, t.mid(), t.mid_flag()));
     }

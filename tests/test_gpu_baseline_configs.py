@@ -148,3 +148,32 @@ print("rccl ok", a[1])
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     proc = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert proc.returncode == 0 and "rccl ok" in proc.stdout, proc.stdout[-1000:] + proc.stderr[-3000:]
+
+
+def test_device_path_runs_in_row_blocks(eng):
+    """More than 2^20 observations: the device path runs block by block (bounded hand-over buffer, pla_capi.hip).  Rows on
+    both sides of the block boundary equal a separate pass over just those rows bit for bit, the aggregate equals the sum of
+    the pointwise values, and the row-index flavour (``pla_psis_loo_rows``) walks its index list in the same blocks."""
+    import math
+
+    import torch
+
+    n, s = (1 << 20) + 4099, 256
+    t = torch.empty((n, s), dtype=torch.float32, device="cuda")
+    eng.fill_synthetic(t, seed=0x5EED0011)
+    m = orc.tail_count(s, 1.0)
+    res = eng.psis_loo(t, m, "psis", 1.0, 0.7)
+    lo = (1 << 20) - 7
+    part = eng.psis_loo(t[lo:lo + 14], m, "psis", 1.0, 0.7)
+    for key in ("diag", "loo_i", "lppd_i"):
+        assert torch.equal(res[key][lo:lo + 14], part[key]), key
+    loo_i = res["loo_i"].cpu().numpy()
+    assert np.isfinite(loo_i).all() and int(res["agg"][0]) == n
+    np.testing.assert_allclose(float(res["agg"][1]), math.fsum(loo_i), rtol=1e-12)
+    sample = np.arange(0, n, 40009)
+    ref = orc.loo_arrays(t[sample].cpu().numpy().astype(np.float64), 1.0)
+    np.testing.assert_allclose(loo_i[sample], ref["loo_i"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(res["diag"].cpu().numpy()[sample], ref["khat"], rtol=1e-9, atol=1e-10)
+    back = torch.arange(n - 1, -1, -1, device="cuda")
+    rev = eng.psis_loo(t, m, "psis", 1.0, 0.7, rows=back)
+    assert torch.equal(rev["loo_i"].flip(0), res["loo_i"]) and torch.equal(rev["diag"].flip(0), res["diag"])
