@@ -490,33 +490,51 @@ struct EQuantParams {
   double* out;          // [n_obs][n_probs]
 };
 
-// smallest key whose cumulative mass (sum of `mass(s)` over draws with key <= it) reaches `target`; *below = mass strictly
-// below that key, *at = mass at it.  Returns false when the total never reaches the target.
-template <int BLOCK, class KeyAt, class MassAt>
-__device__ __forceinline__ bool mass_select(const int S, KeyAt key_at, MassAt mass_at, const double target, double* hist, double* red,
-                                            uint64_t* key_out, double* below, double* at) {
+// smallest key whose cumulative mass (sum of the masses of the draws with key <= it) reaches `target`; *below = mass strictly
+// below that key, *at = mass at it.  `each(f)` calls f(key, mass) for every draw of this thread.  Returns false when the
+// total never reaches the target.
+template <int BLOCK, class Each>
+__device__ __forceinline__ bool mass_select(Each each, const double target, double* hist, double* red, uint64_t* key_out, double* below,
+                                            double* at) {
   const int tid = threadIdx.x;
   uint64_t prefix = 0;
   double base = 0.0;
   for (int shift = 56; shift >= 0; shift -= 8) {
     for (int i = tid; i < 256; i += BLOCK) hist[i] = 0.0;
     __syncthreads();
-    for (int s = tid; s < S; s += BLOCK) {
-      const uint64_t k = key_at(s);
-      if (shift == 56 || (k >> (shift + 8)) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], mass_at(s));
-    }
+    each([&](const uint64_t k, const double mass) {
+      if (shift == 56 || (k >> (shift + 8)) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], mass);
+    });
     __syncthreads();
-    // one thread walks the 256 bins (the walk is short and the order of the additions is then fixed)
-    if (tid == 0) {
-      double cum = base;
-      int d = 0;
-      for (; d < 256; ++d) {
-        if (cum + hist[d] >= target) break;
-        cum += hist[d];
+    // the first wave walks the 256 bins, four per lane: in-lane running sums on top of a shuffle scan of the lane totals (a
+    // fixed order of additions, so the result is reproducible; one thread reading bin after bin was 256 dependent LDS round
+    // trips per level -- 30 000 cycles -- and most of this kernel's time)
+    if (tid < kWave) {
+      const double4 h = *reinterpret_cast<const double4*>(&hist[4 * tid]);
+      const double local = ((h.x + h.y) + h.z) + h.w;
+      double incl = local;
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const double up = __shfl_up(incl, o, kWave);
+        if (tid >= o) incl += up;
       }
-      red[0] = cum;
-      red[1] = (double)d;
-      red[2] = d < 256 ? hist[d] : 0.0;
+      double before = __shfl_up(incl, 1, kWave);  // mass in the bins of the lanes below
+      before = base + (tid == 0 ? 0.0 : before);
+      const double c1 = before + h.x, c2 = c1 + h.y, c3 = c2 + h.z, c4 = c3 + h.w;
+      const int i = c1 >= target ? 0 : (c2 >= target ? 1 : (c3 >= target ? 2 : (c4 >= target ? 3 : 4)));
+      const unsigned long long hit = __ballot(i < 4);
+      const int first = hit ? __ffsll((long long)hit) - 1 : kWave - 1;
+      if (tid == first) {
+        if (hit) {
+          red[0] = i == 0 ? before : (i == 1 ? c1 : (i == 2 ? c2 : c3));
+          red[1] = (double)(4 * tid + i);
+          red[2] = i == 0 ? h.x : (i == 1 ? h.y : (i == 2 ? h.z : h.w));
+        } else {
+          red[0] = c4;  // (the total never reaches the target)
+          red[1] = 256.0;
+          red[2] = 0.0;
+        }
+      }
     }
     __syncthreads();
     const int d = (int)red[1];
@@ -536,7 +554,7 @@ __device__ __forceinline__ bool mass_select(const int S, KeyAt key_at, MassAt ma
 
 template <typename T, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
-  __shared__ double hist[256];
+  __shared__ __attribute__((aligned(32))) double hist[256];
   __shared__ double red[BLOCK / kWave > 4 ? BLOCK / kWave : 4];
   const int tid = threadIdx.x;
   const int S = P.n_draws;
@@ -569,6 +587,36 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
     dev = block_reduce<OpMax, BLOCK>(dev, red);
     const bool flat = !nanw && dev <= kCloseAtol + kCloseRtol * fabs(w0);                 // e_loo.py:536
     const auto wat = [&](int s) { return exp((double)wr[(int64_t)s * P.stride_draw] - mlw) / sa; };
+    // Each thread's draws -- order-preserving key and normalised weight -- stay in its registers for the passes that follow
+    // (up to kKeep per thread: S <= 4096 at 256 threads; longer rows re-read and re-evaluate): the eight radix passes per
+    // level are then LDS atomics only, instead of eight more trips over the row with an exponential and a division per draw.
+    constexpr int kKeep = 16;
+    const bool kept = S <= kKeep * BLOCK;
+    uint64_t kreg[kKeep];
+    double wreg[kKeep];
+    if (kept) {
+#pragma unroll
+      for (int j = 0; j < kKeep; ++j) {
+        const int s = tid + j * BLOCK;
+        kreg[j] = s < S ? key_at(s) : ~0ull;
+        wreg[j] = s < S ? wat(s) : 0.0;
+      }
+    }
+    const auto each = [&](auto f) {  // f(key, weight) for every draw of this thread
+      if (kept) {
+#pragma unroll
+        for (int j = 0; j < kKeep; ++j)
+          if (tid + j * BLOCK < S) f(kreg[j], wreg[j]);
+      } else {
+        for (int s = tid; s < S; s += BLOCK) f(key_at(s), wat(s));
+      }
+    };
+    const auto each_count = [&](auto f) { each([&](const uint64_t k, const double) { f(k, 1.0); }); };
+    double wtot = 0.0;
+    if (!flat) {
+      each([&](const uint64_t, const double w) { wtot += w; });
+      wtot = block_reduce<OpSum, BLOCK>(wtot, red);                                       // e_loo.py:542: cumsum / sum
+    }
     for (int ip = 0; ip < P.n_probs; ++ip) {
       const double prob = P.probs[ip];
       double res;
@@ -578,34 +626,29 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
         // np.quantile(x, prob), method "linear": virtual index (S - 1) prob between the order statistics lo and lo + 1
         const double virt = (double)(S - 1) * prob;
         const double lo = floor(virt), t = virt - lo;
-        const auto one = [](int) { return 1.0; };
-        mass_select<BLOCK>(S, key_at, one, lo + 1.0, hist, red, &kv, &below, &at);
+        mass_select<BLOCK>(each_count, lo + 1.0, hist, red, &kv, &below, &at);
         const double a = val_of(kv);
         double b = a;
         if (below + at < lo + 2.0 && lo + 1.0 < (double)S) {  // the next order statistic is the next distinct value
           double nxt = pinf();
-          for (int s = tid; s < S; s += BLOCK) {
-            const double x = xat(s);
-            if (key_at(s) > kv) nxt = fmin(nxt, x);
-          }
+          each([&](const uint64_t k, const double) {
+            if (k > kv) nxt = fmin(nxt, val_of(k));
+          });
           b = block_reduce<OpMin, BLOCK>(nxt, red);
         }
         const double diff = b - a;
         res = (t >= 0.5) ? b - diff * (1.0 - t) : a + diff * t;                           // numpy's _lerp
         if (t == 0.0) res = a;
       } else {
-        const auto wmass = [&](int s) { return wat(s); };
-        double wtot = 0.0;
-        for (int s = tid; s < S; s += BLOCK) wtot += wat(s);
-        wtot = block_reduce<OpSum, BLOCK>(wtot, red);                                     // e_loo.py:542: cumsum / sum
-        const bool found = mass_select<BLOCK>(S, key_at, wmass, prob * wtot, hist, red, &kv, &below, &at);
+        const bool found = mass_select<BLOCK>(each, prob * wtot, hist, red, &kv, &below, &at);
         if (!found) {
           res = xmax;                                                                     // 545-546
         } else {
           const double v = val_of(kv);
           double prev = -pinf();
-          for (int s = tid; s < S; s += BLOCK)
-            if (key_at(s) < kv) prev = fmax(prev, xat(s));
+          each([&](const uint64_t k, const double) {
+            if (k < kv) prev = fmax(prev, val_of(k));
+          });
           prev = block_reduce<OpMax, BLOCK>(prev, red);
           if (below == 0.0 && prev == -pinf()) res = v;                                   // wi == 0: 548-550
           else {
