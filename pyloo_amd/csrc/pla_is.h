@@ -16,7 +16,10 @@
 
 namespace pla {
 
-template <typename T, int VEC, bool TIS>
+// LW: the weights-returning flavour (compute_importance_weights(method="sis" | "tis"), base.py:146-166): the input is the log
+// ratios themselves (raw = input), the outputs are lw (same dtype as the input) and the ESS; nothing streams in behind the
+// sums -- the registers are stored as lw = min(x, cut) - log A first, each vector replaced by the next row's as it leaves.
+template <typename T, int VEC, bool TIS, bool LW = false>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void is_wave_kernel(RowsParams P, FastParams F) {
   __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];
   __shared__ __attribute__((aligned(16))) double lt[2 * kLogTabN];
@@ -46,18 +49,18 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void is_wave_kernel(Rows
     const double ncopy = (double)((NQ - qfull) - (lane < qrem ? 1 : 0));
     double first[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) first[e] = -(double)v[e];  // raw = -ll
+    for (int e = 0; e < VEC; ++e) first[e] = LW ? (double)v[e] : -(double)v[e];  // raw = -ll (weights mode: the input)
     // ---- statistics ------------------------------------------------------------------------------
     double mx, mn;
     {
-      T cur = (T)(-pinf()), vmx = (T)(-pinf());
+      T cur = (T)(-pinf()), vmx = LW ? (T)pinf() : (T)(-pinf());
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
-        cur = vmax_nc<true>(v[i], cur);
-        vmx = vmax_nc<false>(v[i], vmx);
+        cur = vmax_nc<!LW>(v[i], cur);                                        // max raw
+        vmx = LW ? vmin_nc(v[i], vmx) : vmax_nc<false>(v[i], vmx);            // min raw (LOO: as max ll)
       }
       mx = (double)cur;
-      mn = -(double)vmx;
+      mn = LW ? (double)vmx : -(double)vmx;
     }
     double m, nmn;
     wave_all2<R_MAX>(mx, -mn, m, nmn);  // min = -max(-.)
@@ -70,13 +73,13 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void is_wave_kernel(Rows
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
       double ep, en;
-      exp_pair((-(double)v[i]) - m, tab, ep, en);  // x in [-R, 0], R < 690; a NaN draw poisons the sums -> general kernel
+      exp_pair((LW ? (double)v[i] : -(double)v[i]) - m, tab, ep, en);  // x in [-R, 0], R < 690; a NaN draw poisons the sums -> general kernel
       sa += ep;
       sb = fma(ep, ep, sb);
       sc += en;
       // pin the running sums: otherwise the scheduler starts all 64 independent exponentials at once and spills
       if ((i & 1) == 1) asm volatile("" : "+v"(sa), "+v"(sb), "+v"(sc));
-      if constexpr (!tis)
+      if constexpr (!tis && !LW)
         if ((i % VEC) == VEC - 1) issue_row_vector<T, VEC>(v, rs_next, i / VEC);
     }
     {
@@ -94,6 +97,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void is_wave_kernel(Rows
       sc = fma(-ncopy, c0, sc);
     }
     double A, C, B = 0.0, D = (double)S;
+    double cut_w = 0.0;  // (weights mode, TIS: the truncation point, for the output pass)
     wave_all2<R_SUM>(sa, sc, A, C);
     if constexpr (!tis) {
       B = wave_all<R_SUM>(sb);
@@ -106,12 +110,14 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void is_wave_kernel(Rows
       // cancels badly: A_t >= A / sqrt(S) and B_t >= A^2 / S >= B / S keep all but ~4 of the 16 digits.
       const double cut = (log_tab(A, lt) - log_S) + 0.5 * log_S;
       const double ecut = exp_tab(fmin(fmax(cut, -700.0), 700.0), tab);
+      cut_w = cut;
       B = wave_all<R_SUM>(sb);
       double m2 = m;
       asm volatile("" : "+v"(m2));
       // v < thr  <=>  (-v) - m > cut, up to the rounding of the subtraction: thr is widened, the exact test follows inside
-      const double thr0 = -(m2 + cut);
+      const double thr0 = LW ? (m2 + cut) : -(m2 + cut);  // (weights mode: v > thr  <=>  v - m > cut)
       const double thr = thr0 + fmax(fabs(thr0), fabs(m2)) * 1e-12;
+      const double thr_lw = thr0 - fmax(fabs(thr0), fabs(m2)) * 1e-12;
       double da = 0.0, db = 0.0, dd = 0.0;
       const auto term = [&](double x, double& a, double& b2, double& d) {
         double ep, en;
@@ -123,8 +129,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void is_wave_kernel(Rows
       };
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
-        if (__ballot((double)v[i] < thr) != 0ull) term((-(double)v[i]) - m2, da, db, dd);
-        if ((i % VEC) == VEC - 1) issue_row_vector<T, VEC>(v, rs_next, i / VEC);
+        if (__ballot(LW ? (double)v[i] > thr_lw : (double)v[i] < thr) != 0ull) term((LW ? (double)v[i] : -(double)v[i]) - m2, da, db, dd);
+        if constexpr (!LW)
+          if ((i % VEC) == VEC - 1) issue_row_vector<T, VEC>(v, rs_next, i / VEC);
       }
       {  // the padded slots hold copies of the lane's first vector
         double a0 = 0.0, b0 = 0.0, d0 = 0.0;
@@ -145,15 +152,27 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void is_wave_kernel(Rows
     const double logA = lane_value(lg, 0), logC = lane_value(lg, 1), logD = lane_value(lg, 2);
     loo = ((-m) - logA) + logD;
     lppd = (logC - m) - log_S;
-    if (!isfinite(ess) || !isfinite(loo) || !isfinite(lppd)) slow = true;
+    if (!isfinite(ess) || !isfinite(logA) || (!LW && (!isfinite(loo) || !isfinite(lppd)))) slow = true;
+    if constexpr (LW) {
+      // lw = min(x, cut) - log A (sis.py:101-103, tis.py:112-116), from the registers; the next row's vectors take their place
+      if (!slow) {
+        T* orow = reinterpret_cast<T*>(P.lw_out) + r * (int64_t)S;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(orow, 0, S * (int)sizeof(T), 0x00020000);
+        lw_store_chunk<T, VEC, true, TIS>(v, ro, rs_next, lane, qfull, m, logA, cut_w);
+      } else if (rp_next) {
+        issue_row_loads<T, VEC>(v, rp_next, S);
+      }
+    }
     if (lane == 0) {
       if (slow) {
         const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
         F.slow_list[idx] = (unsigned)r;
       } else {
         if (P.diag) P.diag[r] = ess;
-        if (P.loo_i) P.loo_i[r] = P.scale_value * loo;
-        if (P.lppd_i) P.lppd_i[r] = lppd;
+        if constexpr (!LW) {
+          if (P.loo_i) P.loo_i[r] = P.scale_value * loo;
+          if (P.lppd_i) P.lppd_i[r] = lppd;
+        }
       }
     }
   }

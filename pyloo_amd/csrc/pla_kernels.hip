@@ -377,7 +377,7 @@ static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, int bits,
 }
 
 // SIS / TIS in LOO mode: streaming kernel (pla_is.h) + the general kernel for the rows it declines
-template <typename T, int VEC>
+template <typename T, int VEC, bool LW = false>
 static hipError_t launch_is(const RowsParams& p, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
@@ -385,14 +385,14 @@ static hipError_t launch_is(const RowsParams& p, hipStream_t stream) {
   int64_t grid = (p.n_obs + kWavesPerBlock - 1) / kWavesPerBlock;
   if (grid > 2048 * 8 / kWavesPerBlock) grid = 2048 * 8 / kWavesPerBlock;
   if (p.method == PLA_TIS)
-    hipLaunchKernelGGL((is_wave_kernel<T, VEC, true>), dim3((unsigned)grid), dim3(kWave * kWavesPerBlock), 0, stream, p, f);
+    hipLaunchKernelGGL((is_wave_kernel<T, VEC, true, LW>), dim3((unsigned)grid), dim3(kWave * kWavesPerBlock), 0, stream, p, f);
   else
-    hipLaunchKernelGGL((is_wave_kernel<T, VEC, false>), dim3((unsigned)grid), dim3(kWave * kWavesPerBlock), 0, stream, p, f);
+    hipLaunchKernelGGL((is_wave_kernel<T, VEC, false, LW>), dim3((unsigned)grid), dim3(kWave * kWavesPerBlock), 0, stream, p, f);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   constexpr int BLOCK = 256;
   int64_t g2 = p.n_obs < 1024 ? p.n_obs : 1024;
-  hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK, false>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap),
+  hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK, LW>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap),
                      stream, p);
   return hipGetLastError();
 }
@@ -415,11 +415,9 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream, hipEvent
         return launch_wave<T, WVEC, LW>(p, gsz, kq, bits, chk, stream, after_first, recorded);
       }
     }
-    if constexpr (!LW) {
-      if (path != 1 && unit && waligned && (p.method == PLA_SIS || p.method == PLA_TIS) && p.slow_list && p.counters &&
-          p.n_draws <= kWave * kWaveSlots && p.n_draws >= kWave * WVEC && p.n_obs <= 0xffffffffll)
-        return launch_is<T, WVEC>(p, stream);
-    }
+    if (path != 1 && unit && waligned && (p.method == PLA_SIS || p.method == PLA_TIS) && p.slow_list && p.counters &&
+        p.n_draws <= kWave * kWaveSlots && p.n_draws >= kWave * WVEC && p.n_obs <= 0xffffffffll)
+      return launch_is<T, WVEC, LW>(p, stream);
     {
       // rows beyond one register chunk or tails beyond the small kernel's LDS: the chunked kernel
       // (weights mode: the candidates carry 16-bit draw indices, so rows up to 65 536 draws; two LDS capacities)

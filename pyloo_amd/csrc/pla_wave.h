@@ -489,9 +489,11 @@ __device__ __forceinline__ bool wave_threshold_check(const T (&v)[kWaveSlots], c
 // ---- weights mode, output: lw_s = (raw_s - m) - L for the (up to) 4096 draws held in the row registers, 16 bytes per lane
 // and store (stores past the end of `ro` are dropped).  STREAM: once a vector is stored, the same registers take the vector of
 // the next chunk from `rs_next` (chunked kernel: the row passes through the registers a second time).
-template <typename T, int VEC, bool STREAM>
+// CLAMP: lw_s = min(raw_s - m, xcap) - L (truncated importance sampling, tis.py:107-114).
+template <typename T, int VEC, bool STREAM, bool CLAMP = false>
 __device__ __forceinline__ void lw_store_chunk(T (&v)[kWaveSlots], const __amdgpu_buffer_rsrc_t ro, const __amdgpu_buffer_rsrc_t rs_next,
-                                               const int lane, const int qfull, const double m, const double L) {
+                                               const int lane, const int qfull, const double m, const double L,
+                                               const double xcap = 0.0) {
   constexpr int NQ = kWaveSlots / VEC;
   typedef int v4i __attribute__((ext_vector_type(4)));
 #pragma unroll
@@ -499,12 +501,18 @@ __device__ __forceinline__ void lw_store_chunk(T (&v)[kWaveSlots], const __amdgp
     if (q <= qfull) {  // later vectors lie past the row (stores past the end are dropped anyway)
       v4i t;
       if constexpr (VEC == 2) {
-        const double a0 = ((double)v[2 * q] - m) - L, a1 = ((double)v[2 * q + 1] - m) - L;
+        double x0 = (double)v[2 * q] - m, x1 = (double)v[2 * q + 1] - m;
+        if constexpr (CLAMP) { x0 = fmin(x0, xcap); x1 = fmin(x1, xcap); }
+        const double a0 = x0 - L, a1 = x1 - L;
         t[0] = __double2loint(a0); t[1] = __double2hiint(a0);
         t[2] = __double2loint(a1); t[3] = __double2hiint(a1);
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = __float_as_int((float)(((double)v[4 * q + e] - m) - L));
+        for (int e = 0; e < 4; ++e) {
+          double xe = (double)v[4 * q + e] - m;
+          if constexpr (CLAMP) xe = fmin(xe, xcap);
+          t[e] = __float_as_int((float)(xe - L));
+        }
       }
       __builtin_amdgcn_raw_buffer_store_b128(t, ro, lane * 16, q * (kWave * 16), 0);  // (non-temporal stores measured 5 % slower)
       // gfx9 hazard: a VALU write to the data registers of a > 8-byte buffer store with an SGPR offset

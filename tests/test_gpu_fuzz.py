@@ -95,6 +95,12 @@ def test_random_rows_every_entry_point(eng, seed, S, N, reff, dt):
         g2 = eng.psis_loo(ll, 0, method, 1.0, 0.7)
         close(g2["loo_i"], r2["loo_i"], what=f"loo_i ({method})")
         close(g2["diag"], r2["diag"], rtol=1e-8, what=f"ess ({method})")
+        lw2, ess2 = eng.importance_weights(-ll, 0, method)   # the weights-returning flavour of the same kernel
+        close(ess2, r2["diag"], rtol=1e-8, what=f"ess (weights, {method})")
+        if dt == np.float64:
+            close(lw2, r2["lw"], what=f"lw ({method})")
+        else:
+            close(lw2, r2["lw"].astype(np.float32), rtol=3e-7, atol=2e-7, what=f"lw ({method}, f32)")
     with np.errstate(all="ignore"):
         w = orc.waic_arrays(ll64)
     gw = eng.waic(ll)
