@@ -72,13 +72,15 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void is_wave_kernel(Rows
     double sa = 0.0, sb = 0.0, sc = 0.0;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
-      double ep, en;
-      exp_pair((LW ? (double)v[i] : -(double)v[i]) - m, tab, ep, en);  // x in [-R, 0], R < 690; a NaN draw poisons the sums -> general kernel
+      double ep, en = 0.0;
+      // x in [-R, 0], R < 690; a NaN draw poisons the sums -> general kernel.  (Weights mode has no use for e^-x.)
+      if constexpr (LW) ep = exp_tab((double)v[i] - m, tab);
+      else exp_pair((-(double)v[i]) - m, tab, ep, en);
       sa += ep;
       sb = fma(ep, ep, sb);
       sc += en;
       // pin the running sums: otherwise the scheduler starts all 64 independent exponentials at once and spills
-      if ((i & 1) == 1) asm volatile("" : "+v"(sa), "+v"(sb), "+v"(sc));
+      if (LW || (i & 1) == 1) asm volatile("" : "+v"(sa), "+v"(sb), "+v"(sc));  // (weights mode keeps the whole row live: one draw at a time)
       if constexpr (!tis && !LW)
         if ((i % VEC) == VEC - 1) issue_row_vector<T, VEC>(v, rs_next, i / VEC);
     }
@@ -120,20 +122,38 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void is_wave_kernel(Rows
       const double thr_lw = thr0 - fmax(fabs(thr0), fabs(m2)) * 1e-12;
       double da = 0.0, db = 0.0, dd = 0.0;
       const auto term = [&](double x, double& a, double& b2, double& d) {
-        double ep, en;
-        exp_pair(x, tab, ep, en);
+        double ep, en = 0.0;
+        if constexpr (LW) ep = exp_tab(x, tab);
+        else exp_pair(x, tab, ep, en);
         const bool tr = x > cut;
         a += tr ? ep - ecut : 0.0;
         b2 += tr ? fma(ep, ep, -ecut * ecut) : 0.0;
-        d += tr ? fma(-ecut, en, 1.0) : 0.0;
+        if constexpr (!LW) d += tr ? fma(-ecut, en, 1.0) : 0.0;
       };
+      if constexpr (LW) {
+        // Weights mode keeps the row in the registers for the output pass, so there is no room for 64 conditional
+        // exponentials next to it: one compare per slot collects the lane's candidates in a 64-bit mask, and the few draws it
+        // names are read again from the row in memory (cache hits).  Slots past the row are skipped, not counted and corrected.
+        // (Tried for the LOO pass as well: 6.3 instead of 5.7 ms -- there the conditional blocks ride under the streaming loads.)
+        unsigned long long mask = 0ull;
 #pragma unroll
-      for (int i = 0; i < EPT; ++i) {
-        if (__ballot(LW ? (double)v[i] > thr_lw : (double)v[i] < thr) != 0ull) term((LW ? (double)v[i] : -(double)v[i]) - m2, da, db, dd);
-        if constexpr (!LW)
+        for (int i = 0; i < EPT; ++i) mask |= ((double)v[i] > thr_lw) ? (1ull << i) : 0ull;
+        if (__ballot(mask != 0ull) != 0ull) {
+          const T* rowp = base + PLA_ROW_OFFSET(P, r);
+          while (mask) {
+            const int i = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            const int idx = VEC * (lane + kWave * (i / VEC)) + i % VEC;
+            if (idx < S) term((double)rowp[idx] - m2, da, db, dd);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+          if (__ballot((double)v[i] < thr) != 0ull) term((-(double)v[i]) - m2, da, db, dd);
           if ((i % VEC) == VEC - 1) issue_row_vector<T, VEC>(v, rs_next, i / VEC);
-      }
-      {  // the padded slots hold copies of the lane's first vector
+        }
+        // the padded slots hold copies of the lane's first vector
         double a0 = 0.0, b0 = 0.0, d0 = 0.0;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) term(first[e] - m2, a0, b0, d0);
@@ -155,13 +175,13 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void is_wave_kernel(Rows
     if (!isfinite(ess) || !isfinite(logA) || (!LW && (!isfinite(loo) || !isfinite(lppd)))) slow = true;
     if constexpr (LW) {
       // lw = min(x, cut) - log A (sis.py:101-103, tis.py:112-116), from the registers; the next row's vectors take their place
-      if (!slow) {
-        T* orow = reinterpret_cast<T*>(P.lw_out) + r * (int64_t)S;
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(orow, 0, S * (int)sizeof(T), 0x00020000);
-        lw_store_chunk<T, VEC, true, TIS>(v, ro, rs_next, lane, qfull, m, logA, cut_w);
-      } else if (rp_next) {
-        issue_row_loads<T, VEC>(v, rp_next, S);
-      }
+      // (a declined row goes through the same code with an empty output range -- its stores are dropped -- so that the next
+      // row's loads have ONE place of issue: two of them made the register allocator shuffle the row through scratch)
+      T* orow = reinterpret_cast<T*>(P.lw_out) + r * (int64_t)S;
+      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(orow, 0, slow ? 0 : S * (int)sizeof(T), 0x00020000);
+      double m3 = m;  // laundered: otherwise the shifted values of pass 1 are kept alive for this pass and spill
+      asm volatile("" : "+v"(m3));
+      lw_store_chunk<T, VEC, true, TIS>(v, ro, rs_next, lane, qfull, m3, logA, cut_w);
     }
     if (lane == 0) {
       if (slow) {

@@ -31,8 +31,11 @@ KERNELS = {
     "e_loo_wave_kernelIdLb1": 81920,                   # e_loo, one pass, own log ratios
     "e_loo_wave_kernelIfLb0": 81920,
     "waic_wave_kernelIdLi2": 81920,
-    "is_wave_kernelIdLi2ELb0": 81920,
-    "is_wave_kernelIdLi2ELb1": 81920,
+    "is_wave_kernelIdLi2ELb0ELb0": 81920,              # SIS / TIS, LOO pass
+    "is_wave_kernelIdLi2ELb1ELb0": 81920,
+    "is_wave_kernelIdLi2ELb0ELb1": 81920,              # ... weights out
+    "is_wave_kernelIdLi2ELb1ELb1": 81920,
+    "is_wave_kernelIfLi4ELb1ELb1": 81920,
 }
 
 
