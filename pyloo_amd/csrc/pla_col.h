@@ -29,10 +29,10 @@
 namespace pla {
 
 #ifndef PLA_COL_U
-#define PLA_COL_U 8        // draws per batch; two batches in flight per lane
+#define PLA_COL_U 12       // draws per batch; two batches in flight per lane
 #endif
 #ifndef PLA_COL_WAVES
-#define PLA_COL_WAVES 3    // waves per SIMD the sweep is compiled for
+#define PLA_COL_WAVES 2    // waves per SIMD the sweep is compiled for (its staging rings allow two workgroups per CU)
 #endif
 #ifndef PLA_COL_ILP
 #define PLA_COL_ILP 4      // draws the scheduler may interleave
@@ -41,22 +41,25 @@ namespace pla {
 #define PLA_COL_STORE_AUX 0   // cache policy of the candidate stores
 #endif
 #ifndef PLA_COL_FLUSH
-#define PLA_COL_FLUSH 8       // candidates per store burst: 8 x 8 bytes = half a cache line
+#define PLA_COL_FLUSH 16      // candidates per store burst: 16 x 8 bytes = ONE cache line, written whole
 #endif
 #ifndef PLA_COL_CHECK
-#define PLA_COL_CHECK 8  // draws between two looks at the staging ring (a flush is four store instructions whether or not a lane has a burst ready)
+#define PLA_COL_CHECK PLA_COL_U  // draws between two looks at the staging ring: once per batch (a flush is eight store instructions whether or not a lane has a burst ready)
 #endif
 constexpr int kColFlush = PLA_COL_FLUSH;
 static_assert(PLA_COL_FLUSH - 1 + PLA_COL_CHECK <= 2 * PLA_COL_FLUSH, "the ring must hold what arrives between two checks");
 constexpr int kColRing = 2 * kColFlush;  // staging ring per lane (at most kColFlush - 1 + PLA_COL_CHECK entries wait between two checks)
 constexpr int kColSample = 512;   // draws in the pre-pass: 64 groups of 8
 constexpr int kColCap = 1024;     // candidate list capacity per observation (doubles)
-// Layout of the lists: 64 consecutive observations (the lanes of one sweep wave) share a 512 KB group, interleaved burst by
-// burst -- entry j of observation 64 g + l lies at double  g * 65536 + ((j / 8) * 64 + l) * 8 + j % 8.  The 64-byte bursts
-// the lanes of a wave write at about the same time are then neighbours (a few 4 KB pages per store instruction instead of
-// 64 pages 8 KB apart: address translation and DRAM page locality), at the price of a strided read in the selection.
-__device__ __forceinline__ int64_t col_list_base(int64_t obs) { return (obs >> 6) * (int64_t)(64 * kColCap) + (obs & 63) * 8; }
-__device__ __forceinline__ int col_list_entry(int j) { return (j >> 3) * 512 + (j & 7); }
+// Layout of the lists: 64 consecutive observations (the lanes of one sweep wave) share a 512 KB group, interleaved line by
+// line -- entry j of observation 64 g + l lies at double  g * 65536 + ((j / 16) * 64 + l) * 16 + j % 16.  A flush writes one
+// WHOLE 128-byte line (16 candidates), so no line is ever written in two halves: half-line bursts into these lines took the
+// sweep from 2.0 to 4.7 ms per block (read-modify-write), half-line bursts interleaved per 64 bytes -- the two halves of a
+// line belong to neighbouring lanes -- 2.04 ms, whole lines 1.90 ms although the 32-entry rings leave room for two
+// workgroups per CU, not three.  The lines the lanes of a wave write at about the same time are neighbours (a few pages per
+// store instruction instead of 64 pages 8 KB apart), and the selection reads whole lines.
+__device__ __forceinline__ int64_t col_list_base(int64_t obs) { return (obs >> 6) * (int64_t)(64 * kColCap) + (obs & 63) * 16; }
+__device__ __forceinline__ int col_list_entry(int j) { return (j >> 4) * 1024 + (j & 15); }
 
 struct ColParams {
   const void* in;      // element (observation i, draw s) at in[s * ld + i]
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256, PLA_COL_WAVES) void col_sweep_kernel(ColParams
   // (the lists of this launch's observations: at most 262 144 x 8 KB = 2 GB, inside one descriptor's 32-bit range)
   const __amdgpu_buffer_rsrc_t rs_list = __builtin_amdgcn_make_buffer_rsrc(
       P.cand, 0, (int)(unsigned)(((((P.n_obs + 63) & ~63ll) * (int64_t)kColCap * 8) > 0xfffffff0ll) ? 0xfffffff0ll : ((P.n_obs + 63) & ~63ll) * (int64_t)kColCap * 8), 0x00020000);
-  static_assert(kColFlush == 8, "a flush is one 64-byte burst of the interleaved list layout");
+  static_assert(kColFlush == 16, "a flush is one whole line of the interleaved list layout");
   const int list_off = (int)(col_list_base(live ? i : 0) * 8);
   const char* tabc = reinterpret_cast<const char*>(tab);
   constexpr int U = PLA_COL_U;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256, PLA_COL_WAVES) void col_sweep_kernel(ColParams
   const auto flush4 = [&]() {
     const bool go = cnt - flushed >= kColFlush;
     const bool wr = go & (flushed + kColFlush <= kColCap) & live;  // (bitwise: no short-circuit branches inside the sweep)
-    const int off = wr ? list_off + 512 * flushed : (int)0xffffff00;  // burst flushed / 8, 4 KB apart
+    const int off = wr ? list_off + 8 * col_list_entry(flushed) : (int)0xffffff00;  // (flushed is a multiple of 16: the start of a line)
     const double* src = &mine[flushed & (kColRing - 1)];  // (flushed is a multiple of kColFlush: no wrap inside a burst)
 #pragma unroll
     for (int q = 0; q < kColFlush / 2; ++q)
