@@ -227,8 +227,15 @@ __global__ __launch_bounds__(256, PLA_COL_WAVES) void col_sweep_kernel(ColParams
     flush4();
   }
   flush4();
-  for (int j = flushed; j < cnt && j < kColCap; ++j)  // the last, fewer than a burst, one by one
-    if (live) P.cand[col_list_base(i) + col_list_entry(j)] = mine[j & (kColRing - 1)];
+  {  // the last, partly filled line goes out whole as well (entries past `cnt` are stale ring contents, never read): eight
+     // byte-sized stores into a line that is not complete would each be a read-modify-write
+    const bool wr = (cnt > flushed) & (flushed + kColFlush <= kColCap) & live;
+    const int off = wr ? list_off + 8 * col_list_entry(flushed) : (int)0xffffff00;
+    const double* src = &mine[flushed & (kColRing - 1)];
+#pragma unroll
+    for (int q = 0; q < kColFlush / 2; ++q)
+      __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4i*>(src + 2 * q), rs_list, off, 16 * q, PLA_COL_STORE_AUX);
+  }
   if (live) {
     double* o = P.scal + i * 8;
     o[0] = mp; o[1] = -nmn; o[2] = -nmx; o[3] = s1; o[4] = s2; o[5] = (double)cnt; o[6] = t_raw;
