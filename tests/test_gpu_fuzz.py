@@ -2,6 +2,8 @@
 the oracle on the same inputs.  The fixed cases elsewhere pin known edges; this one walks the dispatch table -- one-chunk,
 chunked, column, general kernels; LOO, weights, SIS / TIS, WAIC, e_loo -- with shapes nobody picked by hand."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -46,7 +48,7 @@ def make_rows(rng, n, s, dt):
     return ll.astype(dt)
 
 
-CONFIGS = [(100 * rep + seed, s, n, reff, dt) for rep in range(3) for seed, (s, n, reff, dt) in enumerate([
+CONFIGS = [(100 * rep + seed, s, n, reff, dt) for rep in range(int(os.environ.get("PYLOO_AMD_FUZZ_REPS", "3"))) for seed, (s, n, reff, dt) in enumerate([
     (256, 37, 1.0, np.float64), (258, 5, 0.7, np.float64), (640, 64, 1.3, np.float32), (1000, 33, 0.5, np.float64),
     (1536, 20, 1.0, np.float32), (2000, 48, 0.31, np.float64), (3000, 17, 1.0, np.float64), (4000, 70, 0.9, np.float32),
     (4096, 9, 1.0, np.float64), (4098, 12, 1.0, np.float64), (4352, 10, 0.8, np.float32), (5000, 21, 1.0, np.float64),
