@@ -493,9 +493,20 @@ struct EQuantParams {
 // smallest key whose cumulative mass (sum of the masses of the draws with key <= it) reaches `target`; *below = mass strictly
 // below that key, *at = mass at it.  `each(f)` calls f(key, mass) for every draw of this thread.  Returns false when the
 // total never reaches the target.
+// After two passes (16 bits of the key: sign, exponent, four bits of mantissa) the bin that holds the target rarely has more
+// than a few dozen draws: they are collected into an LDS list and settled there (every thread of the list takes one element
+// and adds up the masses at or below it) instead of six more passes over all the draws.  A list that does not fit (more than
+// 256 draws share the prefix) goes on with the radix descent and tries again one byte further down.
+struct QuantList {
+  uint64_t key[256];
+  double mass[256];
+  unsigned long long best;
+  int count;
+};
 template <int BLOCK, class Each>
-__device__ __forceinline__ bool mass_select(Each each, const double target, double* hist, double* red, uint64_t* key_out, double* below,
-                                            double* at) {
+__device__ __forceinline__ bool mass_select(Each each, const double target, double* hist, double* red, QuantList* ql, uint64_t* key_out,
+                                            double* below, double* at) {
+  static_assert(BLOCK >= 256, "one thread per list entry");
   const int tid = threadIdx.x;
   uint64_t prefix = 0;
   double base = 0.0;
@@ -543,6 +554,52 @@ __device__ __forceinline__ bool mass_select(Each each, const double target, doub
     __syncthreads();
     if (d >= 256) return false;
     prefix = (prefix << 8) | (uint64_t)d;
+    if (shift <= 48 && shift > 0) {
+      if (tid == 0) {
+        ql->count = 0;
+        ql->best = ~0ull;
+      }
+      __syncthreads();
+      each([&](const uint64_t k, const double mass) {
+        if ((k >> shift) == prefix) {
+          const int idx = atomicAdd(&ql->count, 1);
+          if (idx < 256) {
+            ql->key[idx] = k;
+            ql->mass[idx] = mass;
+          }
+        }
+      });
+      __syncthreads();
+      const int n = ql->count;
+      if (n <= 256) {  // (wave-uniform: every thread reads the same count)
+        uint64_t mine = ~0ull;
+        double upto = base, under = base;
+        if (tid < n) {
+          mine = ql->key[tid];
+          for (int j = 0; j < n; ++j) {
+            const uint64_t kj = ql->key[j];
+            const double mj = ql->mass[j];
+            upto += (kj <= mine) ? mj : 0.0;
+            under += (kj < mine) ? mj : 0.0;
+          }
+        }
+        const bool reaches = tid < n && upto >= target;
+        if (reaches) atomicMin(&ql->best, (unsigned long long)mine);
+        __syncthreads();
+        const uint64_t best = (uint64_t)ql->best;
+        if (best == ~0ull) return false;  // (the total never reaches the target)
+        if (reaches && mine == best) {     // (equal draws compute the same two numbers)
+          red[0] = under;
+          red[2] = upto - under;
+        }
+        __syncthreads();
+        *key_out = best;
+        *below = red[0];
+        *at = red[2];
+        __syncthreads();
+        return true;
+      }
+    }
     if (shift == 0) {
       *key_out = prefix;
       *below = base;
@@ -556,6 +613,7 @@ template <typename T, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
   __shared__ __attribute__((aligned(32))) double hist[256];
   __shared__ double red[BLOCK / kWave > 4 ? BLOCK / kWave : 4];
+  __shared__ QuantList qlist;
   const int tid = threadIdx.x;
   const int S = P.n_draws;
   for (int64_t r = blockIdx.x; r < P.n_obs; r += gridDim.x) {
@@ -563,45 +621,73 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
     const T* wr = reinterpret_cast<const T*>(P.lw) + r * P.stride_obs;
     const auto xat = [&](int s) { return (double)xr[(int64_t)s * P.stride_draw]; };
     const auto key_at = [&](int s) { return key_of(xat(s)); };
-    // normalised weights w = exp(lw - logsumexp(lw)) (e_loo.py:557-559, 473): maximum, sum, and whether they are all close
-    double mlw = -pinf(), xmax = -pinf(), xmin = pinf();
-    unsigned nanw = 0;
-    for (int s = tid; s < S; s += BLOCK) {
-      const double a = (double)wr[(int64_t)s * P.stride_draw];
-      if (a != a) nanw = 1u;
-      mlw = fmax(mlw, a);
-      const double x = xat(s);
-      xmax = fmax(xmax, x);
-      xmin = fmin(xmin, x);
-    }
-    mlw = block_reduce<OpMax, BLOCK>(mlw, red);
-    xmax = block_reduce<OpMax, BLOCK>(xmax, red);
-    xmin = block_reduce<OpMin, BLOCK>(xmin, red);
-    nanw = block_or_bits<BLOCK>(nanw, red);
-    double sa = 0.0;
-    for (int s = tid; s < S; s += BLOCK) sa += exp((double)wr[(int64_t)s * P.stride_draw] - mlw);
-    sa = block_reduce<OpSum, BLOCK>(sa, red);
-    const double w0 = exp((double)wr[0] - mlw) / sa;
-    double dev = 0.0;
-    for (int s = tid; s < S; s += BLOCK) dev = fmax(dev, fabs(exp((double)wr[(int64_t)s * P.stride_draw] - mlw) / sa - w0));
-    dev = block_reduce<OpMax, BLOCK>(dev, red);
-    const bool flat = !nanw && dev <= kCloseAtol + kCloseRtol * fabs(w0);                 // e_loo.py:536
-    const auto wat = [&](int s) { return exp((double)wr[(int64_t)s * P.stride_draw] - mlw) / sa; };
-    // Each thread's draws -- order-preserving key and normalised weight -- stay in its registers for the passes that follow
-    // (up to kKeep per thread: S <= 4096 at 256 threads; longer rows re-read and re-evaluate): the eight radix passes per
-    // level are then LDS atomics only, instead of eight more trips over the row with an exponential and a division per draw.
+    // normalised weights w = exp(lw - logsumexp(lw)) (e_loo.py:557-559, 473): maximum, sum, and whether they are all close.
+    // Each thread's draws -- order-preserving key and normalised weight -- stay in its registers for everything that follows
+    // (up to kKeep per thread: S <= 4096 at 256 threads; longer rows re-read and re-evaluate): ONE trip over the two rows with
+    // all its loads in flight together and one exponential per draw, then LDS atomics only -- instead of four trips with
+    // dependent loads before the first radix pass and an exponential and a division per draw in every pass after it.
     constexpr int kKeep = 16;
     const bool kept = S <= kKeep * BLOCK;
     uint64_t kreg[kKeep];
     double wreg[kKeep];
+    double mlw = -pinf(), xmax = -pinf(), xmin = pinf(), sa = 0.0, dev = 0.0, w0;
+    unsigned nanw = 0;
     if (kept) {
+      double xv[kKeep];
+#pragma unroll
+      for (int j = 0; j < kKeep; ++j) {  // (all 32 loads of the thread go out before anything waits)
+        const int s = tid + j * BLOCK;
+        const int sc = s < S ? s : 0;
+        xv[j] = (double)xr[(int64_t)sc * P.stride_draw];
+        wreg[j] = (double)wr[(int64_t)sc * P.stride_draw];
+      }
 #pragma unroll
       for (int j = 0; j < kKeep; ++j) {
-        const int s = tid + j * BLOCK;
-        kreg[j] = s < S ? key_at(s) : ~0ull;
-        wreg[j] = s < S ? wat(s) : 0.0;
+        const bool in = tid + j * BLOCK < S;
+        if (in && wreg[j] != wreg[j]) nanw = 1u;
+        mlw = in ? fmax(mlw, wreg[j]) : mlw;
+        xmax = in ? fmax(xmax, xv[j]) : xmax;
+        xmin = in ? fmin(xmin, xv[j]) : xmin;
+        kreg[j] = in ? key_of(xv[j]) : ~0ull;
       }
+      mlw = block_reduce<OpMax, BLOCK>(mlw, red);
+      xmax = block_reduce<OpMax, BLOCK>(xmax, red);
+      xmin = block_reduce<OpMin, BLOCK>(xmin, red);
+      nanw = block_or_bits<BLOCK>(nanw, red);
+#pragma unroll
+      for (int j = 0; j < kKeep; ++j) {
+        wreg[j] = tid + j * BLOCK < S ? exp(wreg[j] - mlw) : 0.0;
+        sa += wreg[j];
+      }
+      sa = block_reduce<OpSum, BLOCK>(sa, red);
+      w0 = exp((double)wr[0] - mlw) / sa;
+#pragma unroll
+      for (int j = 0; j < kKeep; ++j) {
+        wreg[j] = wreg[j] / sa;
+        dev = tid + j * BLOCK < S ? fmax(dev, fabs(wreg[j] - w0)) : dev;
+      }
+      dev = block_reduce<OpMax, BLOCK>(dev, red);
+    } else {
+      for (int s = tid; s < S; s += BLOCK) {
+        const double a = (double)wr[(int64_t)s * P.stride_draw];
+        if (a != a) nanw = 1u;
+        mlw = fmax(mlw, a);
+        const double x = xat(s);
+        xmax = fmax(xmax, x);
+        xmin = fmin(xmin, x);
+      }
+      mlw = block_reduce<OpMax, BLOCK>(mlw, red);
+      xmax = block_reduce<OpMax, BLOCK>(xmax, red);
+      xmin = block_reduce<OpMin, BLOCK>(xmin, red);
+      nanw = block_or_bits<BLOCK>(nanw, red);
+      for (int s = tid; s < S; s += BLOCK) sa += exp((double)wr[(int64_t)s * P.stride_draw] - mlw);
+      sa = block_reduce<OpSum, BLOCK>(sa, red);
+      w0 = exp((double)wr[0] - mlw) / sa;
+      for (int s = tid; s < S; s += BLOCK) dev = fmax(dev, fabs(exp((double)wr[(int64_t)s * P.stride_draw] - mlw) / sa - w0));
+      dev = block_reduce<OpMax, BLOCK>(dev, red);
     }
+    const bool flat = !nanw && dev <= kCloseAtol + kCloseRtol * fabs(w0);                 // e_loo.py:536
+    const auto wat = [&](int s) { return exp((double)wr[(int64_t)s * P.stride_draw] - mlw) / sa; };
     const auto each = [&](auto f) {  // f(key, weight) for every draw of this thread
       if (kept) {
 #pragma unroll
@@ -626,7 +712,7 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
         // np.quantile(x, prob), method "linear": virtual index (S - 1) prob between the order statistics lo and lo + 1
         const double virt = (double)(S - 1) * prob;
         const double lo = floor(virt), t = virt - lo;
-        mass_select<BLOCK>(each_count, lo + 1.0, hist, red, &kv, &below, &at);
+        mass_select<BLOCK>(each_count, lo + 1.0, hist, red, &qlist, &kv, &below, &at);
         const double a = val_of(kv);
         double b = a;
         if (below + at < lo + 2.0 && lo + 1.0 < (double)S) {  // the next order statistic is the next distinct value
@@ -640,7 +726,7 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
         res = (t >= 0.5) ? b - diff * (1.0 - t) : a + diff * t;                           // numpy's _lerp
         if (t == 0.0) res = a;
       } else {
-        const bool found = mass_select<BLOCK>(each, prob * wtot, hist, red, &kv, &below, &at);
+        const bool found = mass_select<BLOCK>(each, prob * wtot, hist, red, &qlist, &kv, &below, &at);
         if (!found) {
           res = xmax;                                                                     // 545-546
         } else {
