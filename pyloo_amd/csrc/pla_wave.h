@@ -1276,9 +1276,13 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
 #if PLA_WAVE_ABLATE
   int why_cand = 0;
 #endif
+  // LOO mode sweeps EVERY row, also the ones already lost to the general kernel (their sums and candidates are garbage and
+  // are not looked at): the sweep is where the next row's loads are issued, and a second place of issue for the rows that
+  // skip it made the register allocator merge two copies of the row at the end of every row -- a vmcnt(0) wait and 116
+  // register moves per row in the generated code.  (Weights mode issues them in one place anyway, after its output pass.)
   if (dbgs & 16) {
     loo = t1 + R;  // ablation: statistics and threshold only
-  } else if (!slow) {
+  } else if (!LW || !slow) {
     // bins over the candidates: (k - k1) >> sh  in [0, 511] for k in [k1, 0]
     const int span = -k1;
     const int sh = (span >> 9) ? (32 - __builtin_clz((unsigned)(span >> 9))) : 0;
@@ -1401,7 +1405,9 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       }
     }
     wave_sync();
-    if (dbgs & 4) {
+    if (slow) {
+      // (nothing: the row is on its way to the general kernel)
+    } else if (dbgs & 4) {
       loo = s1;
       lppd = s2;
     } else if ((int)ncand < M + 1 || ncand > (unsigned)kCand) {
@@ -1419,7 +1425,9 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   // the next row starts streaming into the (now dead) row registers while the outputs are stored and
   // the other wave of this SIMD computes
   PLA_PHASE(15);
-  if (!streamed && rp_next) issue_row_loads<T, VEC, LW ? 0 : PLA_LOAD_AUX>(v, rp_next, S);  // rows that never reached the sweep (weights mode: every row)
+  if constexpr (LW || PLA_WAVE_ABLATE) {
+    if (!streamed && rp_next) issue_row_loads<T, VEC, LW ? 0 : PLA_LOAD_AUX>(v, rp_next, S);  // (weights mode: every row)
+  }
   if (lane == 0) {
     if (slow) {
       const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
