@@ -52,6 +52,7 @@ struct FastParams {
   double* ws_y = nullptr;         // [n_obs][ws_stride] ascending tail values
   double* ws_s = nullptr;         // [n_obs][8] scalars
   int ws_stride = 0;
+  unsigned slow_base = 0;         // added to the row numbers written to slow_list (pipelined pass: one list for all blocks)
 };
 
 }  // namespace pla

@@ -61,6 +61,7 @@ struct FitParams {
   double* lppd_i;
   unsigned* slow_list;
   unsigned long long* counters;
+  unsigned slow_base = 0;  // added to the row numbers written to slow_list
 };
 
 // reduction over the 16 lanes of a DPP row; every lane of the row ends up with the (bitwise identical) result
@@ -81,15 +82,21 @@ __device__ __forceinline__ int row_all_add(int v) {
 }
 
 // NQ: 64-value blocks of the tail (4 NQ values per lane); G: grid points per lane (16 G >= m_est); W: waves per workgroup
-template <int NQ, int G = 3, int W = kFitWaves>
-__global__ __launch_bounds__(kWave * W, PLA_FIT_MIN_WAVES) void fit_rows_kernel(FitParams Q) {
+// DYN: the coefficient scratch is the kernel's dynamic LDS (fit_coef_bytes).  The compiler then cannot see that LDS caps the
+// kernel at three waves per SIMD and holds the register budget its launch bounds ask for instead of relaxing it to that cap.
+template <int NQ, int W>
+constexpr size_t fit_coef_bytes() { return (size_t)W * 5 * 4 * (16 * NQ) * sizeof(double); }
+template <int NQ, int G, int W, bool DYN = false>
+__device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
   constexpr int kFitWaves = W;  // (shadows the default: everything below is per instantiation)
   __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];
   __shared__ __attribute__((aligned(16))) double lt[2 * kLogTabN];
   __shared__ __attribute__((aligned(16))) double l1s[64 * NQ];
 #if PLA_FIT_MFMA
   constexpr int QN = 16 * NQ;  // quads per observation
-  __shared__ __attribute__((aligned(16))) double coef[kFitWaves * 5 * 4 * QN];  // per wave [coefficient k][observation][quad]
+  extern __shared__ __attribute__((aligned(16))) double coef_dyn[];
+  __shared__ __attribute__((aligned(16))) double coef_static[DYN ? 2 : kFitWaves * 5 * 4 * QN];  // per wave [coefficient k][observation][quad]
+  double* const coef = DYN ? coef_dyn : coef_static;
 #else
   __shared__ __attribute__((aligned(16))) double coef[kFitWaves * 4 * 16 * NQ * kFitCoefStride];
 #endif
@@ -148,7 +155,12 @@ __global__ __launch_bounds__(kWave * W, PLA_FIT_MIN_WAVES) void fit_rows_kernel(
   }
   const double g_first = Q.b_grid[0], g_last = Q.b_grid[mestM - 1];
   const int64_t ngroups = (Q.n_obs + 3) >> 2;
+  const int t_lane = t;
   for (int64_t grp = (int64_t)blockIdx.x * kFitWaves + wv; grp < ngroups; grp += (int64_t)gridDim.x * kFitWaves) {
+    // (opaque per group: the ranks, table offsets and LDS addresses derived from the lane number are then computed where they
+    // are used instead of being hoisted above the loop, where a dozen of them sit on the register budget of the slim variant)
+    int t = t_lane;
+    if constexpr (DYN) asm volatile("" : "+v"(t));
     const int64_t r0 = grp * 4 + rho;
     const bool inrange = r0 < Q.n_obs;
     const int64_t r = inrange ? r0 : Q.n_obs - 1;
@@ -451,7 +463,7 @@ __global__ __launch_bounds__(kWave * W, PLA_FIT_MIN_WAVES) void fit_rows_kernel(
     if (handled && t == 0) {
       if (slow) {
         const unsigned long long idx = atomicAdd(&Q.counters[0], 1ull);
-        Q.slow_list[idx] = (unsigned)r;
+        Q.slow_list[idx] = (unsigned)r + Q.slow_base;
       } else {
         if (Q.diag) Q.diag[r] = fit ? khat : INF;
         if (Q.loo_i) Q.loo_i[r] = Q.scale_value * loo;
@@ -459,6 +471,22 @@ __global__ __launch_bounds__(kWave * W, PLA_FIT_MIN_WAVES) void fit_rows_kernel(
       }
     }
   }
+}
+
+template <int NQ, int G = 3, int W = kFitWaves>
+__global__ __launch_bounds__(kWave * W, PLA_FIT_MIN_WAVES) void fit_rows_kernel(FitParams Q) {
+  fit_rows_body<NQ, G, W>(Q);
+}
+
+// The same fit for the pipelined pass (pla_capi.hip): it runs BESIDE the wave kernel of the next block of observations, in
+// what that kernel leaves free on a CU -- 512 - 2 x 192 = 128 vector registers per SIMD and 160 KB - 2 x 66 KB of LDS -- so it
+// is compiled for at most 128 registers and two waves per workgroup (half the coefficient scratch: 25 KB of LDS in all).
+#ifndef PLA_FIT_SLIM_WAVES
+#define PLA_FIT_SLIM_WAVES 4  // waves per SIMD the register budget is derived from: 4 -> 128 registers (5 -> 96: spills)
+#endif
+template <int NQ, int G = 3, int W = 2>
+__global__ __launch_bounds__(kWave * W, PLA_FIT_SLIM_WAVES) void fit_rows_slim_kernel(FitParams Q) {
+  fit_rows_body<NQ, G, W, true>(Q);
 }
 
 }  // namespace pla

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(BLOCK) void slow_rows_kernel(RowsParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const Smem sm = carve<BLOCK>(smem_raw, P.tail_cap);
   const unsigned long long count = P.counters[0];
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&P.counters[1], count);  // running total of this call
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(P.slow_total ? P.slow_total : &P.counters[1], count);  // running total of this call
   for (unsigned long long i = blockIdx.x; i < count; i += gridDim.x) {
     const int64_t r = (int64_t)P.slow_list[i];
     const T* rp = reinterpret_cast<const T*>(P.in) + PLA_ROW_OFFSET(P, r);
@@ -255,10 +255,24 @@ static int64_t wave_grid(int64_t n_obs, int waves) {
 }
 
 // second kernel of a split LOO pass: fit / smoothing / outputs for the tails the selection kernel handed over (pla_fit.h)
-static hipError_t launch_fit(const RowsParams& p, const FastParams& f, int mestM, hipStream_t stream) {
+static hipError_t launch_fit(const RowsParams& p, const FastParams& f, int mestM, hipStream_t stream, bool slim = false) {
   FitParams q{p.ws_y, p.ws_s, p.ws_stride, p.n_obs, p.n_draws, p.tail_count, mestM, f.log_S, p.scale_value, p.l1_table,
               p.l1_table + p.tail_count, p.diag, p.loo_i, p.lppd_i, p.slow_list, p.counters};
+  q.slow_base = f.slow_base;
   const int nq = p.ws_stride / 64;
+  if (slim && nq <= 4) {
+    // pipelined pass: one two-wave workgroup per CU fits beside the wave kernel's two; every wave walks many groups
+    int64_t g = ((p.n_obs + 3) / 4 + 1) / 2;
+    if (g > 256 * 4) g = 256 * 4;
+    const dim3 sg((unsigned)g), sb(kWave * 2);
+    switch (nq) {  // (the coefficient scratch is dynamic LDS: pla_fit.h, DYN)
+      case 1: hipLaunchKernelGGL(fit_rows_slim_kernel<1>, sg, sb, (fit_coef_bytes<1, 2>()), stream, q); break;
+      case 2: hipLaunchKernelGGL(fit_rows_slim_kernel<2>, sg, sb, (fit_coef_bytes<2, 2>()), stream, q); break;
+      case 3: hipLaunchKernelGGL(fit_rows_slim_kernel<3>, sg, sb, (fit_coef_bytes<3, 2>()), stream, q); break;
+      default: hipLaunchKernelGGL(fit_rows_slim_kernel<4>, sg, sb, (fit_coef_bytes<4, 2>()), stream, q); break;
+    }
+    return hipGetLastError();
+  }
   const int waves = nq <= 4 ? kFitWaves : 2;
   int64_t g3 = ((p.n_obs + 3) / 4 + waves - 1) / waves;  // four observations per wave
   if (g3 > 256 * 8) g3 = 256 * 8;
@@ -281,10 +295,10 @@ static bool split_ok(const RowsParams& p, int mestM) {
 }
 
 template <typename T, int VEC, bool LW>
-static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, const ThresholdCheck& chk, hipStream_t stream,
-                              hipEvent_t after_first, bool* recorded) {
-  hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
-  if (e != hipSuccess) return e;
+static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, const ThresholdCheck& chk, hipStream_t stream_in,
+                              hipEvent_t after_first, bool* recorded, const PipeStreams* pipe, int* plan) {
+  hipStream_t stream = pipe ? pipe->first : stream_in;
+  hipError_t e = hipSuccess;
   static const int dbg = debug_flag("PLA_DEBUG_SKIP");
   static const int fused = debug_flag("PLA_FUSED");  // 1: single fused kernel (the pre-split pass), for A/B runs
   int root_ = (int)std::sqrt((double)p.tail_count);
@@ -298,20 +312,37 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, co
   // 256 CUs (8 waves each) busy with a short tail
   const int64_t grid = wave_grid(p.n_obs, kWavesPerBlock);
   const bool split = !LW && !fused && !(dbg & 31) && p.ws_stride <= 256 && split_ok(p, mestM);  // (ablation bits >= 32 live inside the split pass)
+  if (plan) {
+    *plan = split ? 1 : 0;
+    return hipSuccess;
+  }
+  if (!(pipe && split)) {  // (pipelined split pass: one counter for all blocks, reset by the caller)
+    e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+  }
   if constexpr (!LW) {
     if (split) {
+      if (pipe) f.slow_base = pipe->slow_base;
       // split pass: wave kernel up to the exact selection, then sixteen lanes per observation for the GPD fit,
       // the smoothing sums and the outputs (pla_fit.h)
       f.ws_y = p.ws_y;
       f.ws_s = p.ws_s;
       f.ws_stride = p.ws_stride;
+      if (pipe && pipe->before_first) (void)hipEventRecord(pipe->before_first, stream);
       hipLaunchKernelGGL((wave_loo_kernel<T, VEC, false, CapsSmall, true>), dim3((unsigned)grid), dim3(kWave * kWavesPerBlock), 0,
                          stream, p, f);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
       if (after_first && hipEventRecord(after_first, stream) == hipSuccess && recorded) *recorded = true;
-      e = launch_fit(p, f, mestM, stream);
+      if (pipe) {  // the fit and the general kernel run on the second stream, beside the next block's first kernel
+        e = hipEventRecord(pipe->first_done, stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(pipe->second, pipe->first_done, 0);
+        if (e != hipSuccess) return e;
+        stream = pipe->second;
+      }
+      e = launch_fit(p, f, mestM, stream, pipe && pipe->slim_fit);
       if (e != hipSuccess) return e;
+      if (pipe) return hipSuccess;  // (the general kernel runs once, behind the last block)
     }
   }
   if (!split) {
@@ -329,10 +360,10 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, co
 
 // long rows (chunks of 4096 draws) and / or tail counts up to 512: pla_chunked.h
 template <typename T, int VEC, class CAP, bool LW = false>
-static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, int bits, const ThresholdCheck& chk, hipStream_t stream,
-                                 hipEvent_t after_first, bool* recorded) {
-  hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
-  if (e != hipSuccess) return e;
+static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, int bits, const ThresholdCheck& chk, hipStream_t stream_in,
+                                 hipEvent_t after_first, bool* recorded, const PipeStreams* pipe, int* plan) {
+  hipStream_t stream = pipe ? pipe->first : stream_in;
+  hipError_t e = hipSuccess;
   static const int fused = debug_flag("PLA_FUSED");
   int root_ = (int)std::sqrt((double)p.tail_count);
   while (root_ * root_ > p.tail_count) --root_;
@@ -346,17 +377,34 @@ static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, int bits,
   if (grid > 2048 * 8 / W) grid = 2048 * 8 / W;
   bool split = false;
   if constexpr (CAP::kMaxTail <= 448 && !LW) split = !fused && split_ok(p, mestM) && p.ws_stride <= 64 * ((CAP::kMaxTail + 63) / 64);
+  if (plan) {
+    *plan = split ? 1 : 0;
+    return hipSuccess;
+  }
+  if (!(pipe && split)) {
+    e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+  }
   if (split) {
     if constexpr (CAP::kMaxTail <= 448 && !LW) {
+      if (pipe) f.slow_base = pipe->slow_base;
       f.ws_y = p.ws_y;
       f.ws_s = p.ws_s;
       f.ws_stride = p.ws_stride;
+      if (pipe && pipe->before_first) (void)hipEventRecord(pipe->before_first, stream);
       hipLaunchKernelGGL((wave_loo_chunked_kernel<T, VEC, CAP, true>), dim3((unsigned)grid), dim3(kWave * W), 0, stream, p, f);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
       if (after_first && hipEventRecord(after_first, stream) == hipSuccess && recorded) *recorded = true;
-      e = launch_fit(p, f, mestM, stream);
+      if (pipe) {
+        e = hipEventRecord(pipe->first_done, stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(pipe->second, pipe->first_done, 0);
+        if (e != hipSuccess) return e;
+        stream = pipe->second;
+      }
+      e = launch_fit(p, f, mestM, stream, pipe && pipe->slim_fit);
       if (e != hipSuccess) return e;
+      if (pipe) return hipSuccess;
     }
   } else {
     hipLaunchKernelGGL((wave_loo_chunked_kernel<T, VEC, CAP, false, LW>), dim3((unsigned)grid), dim3(kWave * W), 0, stream, p, f);
@@ -398,7 +446,9 @@ static hipError_t launch_is(const RowsParams& p, hipStream_t stream) {
 }
 
 template <typename T, bool LW>
-static hipError_t launch_typed(const RowsParams& p, hipStream_t stream, hipEvent_t after_first, bool* recorded) {
+static hipError_t launch_typed(const RowsParams& p, hipStream_t stream, hipEvent_t after_first, bool* recorded,
+                               const PipeStreams* pipe = nullptr, int* plan = nullptr) {
+  if (plan) *plan = 0;
   constexpr int BLOCK = 256;
   const bool unit = (p.stride_draw == 1);
   {
@@ -412,12 +462,12 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream, hipEvent
       int gsz = 0, kq = 0, bits = 0;
       ThresholdCheck chk{};
       if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk)) {
-        return launch_wave<T, WVEC, LW>(p, gsz, kq, bits, chk, stream, after_first, recorded);
+        return launch_wave<T, WVEC, LW>(p, gsz, kq, bits, chk, stream, after_first, recorded, pipe, plan);
       }
     }
     if (path != 1 && unit && waligned && (p.method == PLA_SIS || p.method == PLA_TIS) && p.slow_list && p.counters &&
         p.n_draws <= kWave * kWaveSlots && p.n_draws >= kWave * WVEC && p.n_obs <= 0xffffffffll)
-      return launch_is<T, WVEC, LW>(p, stream);
+      return plan ? hipSuccess : launch_is<T, WVEC, LW>(p, pipe ? pipe->first : stream);
     {
       // rows beyond one register chunk or tails beyond the small kernel's LDS: the chunked kernel
       // (weights mode: the candidates carry 16-bit draw indices, so rows up to 65 536 draws; two LDS capacities)
@@ -431,29 +481,58 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream, hipEvent
           // (f32 rows: six waves per CU; f64 rows need more than 256 registers per lane next to the row, so four)
           using CapLW = std::conditional_t<sizeof(T) == 4, CapsMidLW, CapsMid>;
           if (p.tail_count <= CapLW::kMaxTail && wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk, CapLW::kCand))
-            return launch_chunked<T, WVEC, CapLW, true>(p, gsz, kq, bits, chk, stream, after_first, recorded);
+            return launch_chunked<T, WVEC, CapLW, true>(p, gsz, kq, bits, chk, stream, after_first, recorded, pipe, plan);
           if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk, CapsBig::kCand))
-            return launch_chunked<T, WVEC, CapsBig, true>(p, gsz, kq, bits, chk, stream, after_first, recorded);
+            return launch_chunked<T, WVEC, CapsBig, true>(p, gsz, kq, bits, chk, stream, after_first, recorded, pipe, plan);
         } else {
         if (p.tail_count <= CapsMid4::kMaxTail && wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk, CapsMid4::kCand))
-          return launch_chunked<T, WVEC, CapsMid4>(p, gsz, kq, bits, chk, stream, after_first, recorded);
+          return launch_chunked<T, WVEC, CapsMid4>(p, gsz, kq, bits, chk, stream, after_first, recorded, pipe, plan);
         if (p.tail_count <= CapsMid::kMaxTail && wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk, CapsMid::kCand))
-          return launch_chunked<T, WVEC, CapsMid>(p, gsz, kq, bits, chk, stream, after_first, recorded);
+          return launch_chunked<T, WVEC, CapsMid>(p, gsz, kq, bits, chk, stream, after_first, recorded, pipe, plan);
         if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk, CapsBig::kCand))
-          return launch_chunked<T, WVEC, CapsBig>(p, gsz, kq, bits, chk, stream, after_first, recorded);
+          return launch_chunked<T, WVEC, CapsBig>(p, gsz, kq, bits, chk, stream, after_first, recorded, pipe, plan);
         }
       }
     }
+    if (plan) return hipSuccess;
+    if (pipe) stream = pipe->first;
     if (path == 1) return launch_one<T, BLOCK, 0, LW>(p, stream);
   }
   if (unit && p.n_draws <= BLOCK * 16 && p.n_draws > BLOCK * 4) return launch_one<T, BLOCK, 16, LW>(p, stream);
   return launch_one<T, BLOCK, 0, LW>(p, stream);
 }
 
-hipError_t launch_rows(const RowsParams& p, int dtype, bool lw_mode, hipStream_t stream, hipEvent_t after_first, bool* recorded) {
+hipError_t launch_rows(const RowsParams& p, int dtype, bool lw_mode, hipStream_t stream, hipEvent_t after_first, bool* recorded,
+                       const PipeStreams* pipe) {
   if (p.n_obs <= 0) return hipSuccess;
-  if (dtype == PLA_F64) return lw_mode ? launch_typed<double, true>(p, stream, after_first, recorded) : launch_typed<double, false>(p, stream, after_first, recorded);
-  return lw_mode ? launch_typed<float, true>(p, stream, after_first, recorded) : launch_typed<float, false>(p, stream, after_first, recorded);
+  if (dtype == PLA_F64)
+    return lw_mode ? launch_typed<double, true>(p, stream, after_first, recorded, pipe) : launch_typed<double, false>(p, stream, after_first, recorded, pipe);
+  return lw_mode ? launch_typed<float, true>(p, stream, after_first, recorded, pipe) : launch_typed<float, false>(p, stream, after_first, recorded, pipe);
+}
+
+template <typename T>
+static hipError_t launch_slow_typed(const RowsParams& p, hipStream_t stream) {
+  int64_t g2 = p.n_obs < 1024 ? p.n_obs : 1024;
+  if (p.n_draws >= 8192) {  // (long rows: the latency of one workgroup walking one row, see launch_chunked)
+    constexpr int BLOCK = 1024;
+    hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK, false>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap), stream, p);
+  } else {
+    constexpr int BLOCK = 256;
+    hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK, false>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap), stream, p);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_slow_rows(const RowsParams& p, int dtype, hipStream_t stream) {
+  if (p.n_obs <= 0) return hipSuccess;
+  return dtype == PLA_F64 ? launch_slow_typed<double>(p, stream) : launch_slow_typed<float>(p, stream);
+}
+
+bool rows_split_planned(const RowsParams& p, int dtype) {
+  if (p.n_obs <= 0) return false;
+  int plan = 0;
+  if (dtype == PLA_F64) (void)launch_typed<double, false>(p, nullptr, nullptr, nullptr, nullptr, &plan);
+  else (void)launch_typed<float, false>(p, nullptr, nullptr, nullptr, nullptr, &plan);
+  return plan != 0;
 }
 
 template <typename T>

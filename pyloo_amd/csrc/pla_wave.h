@@ -1112,6 +1112,15 @@ __device__ __forceinline__ void wave_select_split(const FastParams& F, SM& sm, c
   if (ablate_exit(64)) return;
   PLA_PHASE(6);
   // ---- candidates at / above the boundary bin -> sa, grouped by bin (descending bins): all the slot requests at once -----
+  // (the candidates are read from the list a second time rather than held in registers across the scan: that stretch is where
+  // the kernel's register count peaks, and sixteen registers less there let the fit kernel of the previous block of
+  // observations run beside this kernel -- pla_capi.hip, pipelined pass)
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const unsigned c = lane + kWave * u;
+    xs[u] = cs.at(c < ncand ? c : 0);
+  }
   unsigned old[U], st[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -1431,7 +1440,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   if (lane == 0) {
     if (slow) {
       const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
-      F.slow_list[idx] = (unsigned)r;
+      F.slow_list[idx] = (unsigned)r + F.slow_base;
 #if PLA_WAVE_ABLATE
       {  // why the row left the fast path (profiling builds: PLA_PRINT_REASONS)
         int why = 7;  // selection / outputs
