@@ -313,11 +313,13 @@ def weighted_variance_row(x, w):
     return max((mean_sq - mean**2) / (1 - wss), 0.0)
 
 
-def weighted_quantile_row(x, w, prob):
-    """e_loo.py:534-554."""
+def weighted_quantile_row(x, w, prob, stable=False):
+    """e_loo.py:534-554.  ``stable=True`` orders equal draws by index (the reference's ``np.argsort`` is unstable, so which
+    of a group of equal draws comes first -- the only one that interpolates from the value below -- is arbitrary there; the
+    engine takes the lowest index)."""
     if np.allclose(w, w[0]):
         return np.quantile(x, prob)
-    order = np.argsort(x)
+    order = np.argsort(x, kind="stable") if stable else np.argsort(x)
     xs, ws = x[order], w[order]
     ww = np.cumsum(ws) / np.sum(ws)
     ids = np.where(ww >= prob)[0]

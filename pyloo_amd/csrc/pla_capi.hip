@@ -84,14 +84,14 @@ struct pla_engine {
   long long first_launches = 0;
   int64_t launches = 0;
   int pending = 0;  // event pairs recorded and not yet read back
-  // pipelined split pass (psis_loo_impl): two internal streams forked from / joined to the caller's stream and a ring of
-  // hand-over buffers, one per block of observations in flight
-  static constexpr int kPipeRing = 4;
+  // streamed split pass (psis_loo_impl, pla_kernels.hip launch_wave): two internal streams forked from / joined to the
+  // caller's stream -- the wave kernel on one, the fit kernel beside it on the other -- and the flags between them
   hipStream_t pipe_first = nullptr, pipe_second = nullptr;
   hipEvent_t pipe_fork = nullptr, pipe_join1 = nullptr, pipe_join2 = nullptr;
-  hipEvent_t pipe_first_done[kPipeRing] = {}, pipe_second_done[kPipeRing] = {};
-  // timing of the first kernel of each block (bench roofline: average duration of one launch of the dominant kernel)
-  static constexpr int kPipeTimed = 256;
+  void* d_sync = nullptr;
+  size_t d_sync_bytes = 0;
+  // timing of the first kernel alone (bench roofline: average duration of one launch of the dominant kernel)
+  static constexpr int kPipeTimed = 64;
   hipEvent_t pipe_t0[kPipeTimed] = {}, pipe_t1[kPipeTimed] = {};
   int pipe_timed = 0;
 };
@@ -221,24 +221,20 @@ struct TimedLaunch {  // brackets the main kernel with events when timing is on
   }
 };
 
-// streams and events of the pipelined pass, created on first use
+// streams and events of the streamed pass, created on first use
 int ensure_pipe(pla_engine* e) {
   if (e->pipe_first) return PLA_OK;
-  if (g_frozen) return fail(PLA_ERR_FROZEN, "the engine is frozen and has no pipeline streams yet");
+  if (g_frozen) return fail(PLA_ERR_FROZEN, "the engine is frozen and has no internal streams yet");
   hipError_t he = hipStreamCreateWithFlags(&e->pipe_first, hipStreamNonBlocking);
   if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->pipe_second, hipStreamNonBlocking);
   if (he == hipSuccess) he = hipEventCreateWithFlags(&e->pipe_fork, hipEventDisableTiming);
   if (he == hipSuccess) he = hipEventCreateWithFlags(&e->pipe_join1, hipEventDisableTiming);
   if (he == hipSuccess) he = hipEventCreateWithFlags(&e->pipe_join2, hipEventDisableTiming);
-  for (int i = 0; i < pla_engine::kPipeRing && he == hipSuccess; ++i) {
-    he = hipEventCreateWithFlags(&e->pipe_first_done[i], hipEventDisableTiming);
-    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->pipe_second_done[i], hipEventDisableTiming);
-  }
   for (int i = 0; i < pla_engine::kPipeTimed && he == hipSuccess; ++i) {
     he = hipEventCreate(&e->pipe_t0[i]);
     if (he == hipSuccess) he = hipEventCreate(&e->pipe_t1[i]);
   }
-  if (he != hipSuccess) return fail(PLA_ERR_HIP, "pipeline streams / events: %s", hipGetErrorString(he));
+  if (he != hipSuccess) return fail(PLA_ERR_HIP, "internal streams / events: %s", hipGetErrorString(he));
   return PLA_OK;
 }
 
@@ -310,12 +306,9 @@ int pla_engine_destroy(pla_engine* e) {
   }
   if (e->pipe_first) (void)hipStreamDestroy(e->pipe_first);
   if (e->pipe_second) (void)hipStreamDestroy(e->pipe_second);
+  if (e->d_sync) (void)hipFree(e->d_sync);
   for (hipEvent_t ev : {e->pipe_fork, e->pipe_join1, e->pipe_join2})
     if (ev) (void)hipEventDestroy(ev);
-  for (int i = 0; i < pla_engine::kPipeRing; ++i) {
-    if (e->pipe_first_done[i]) (void)hipEventDestroy(e->pipe_first_done[i]);
-    if (e->pipe_second_done[i]) (void)hipEventDestroy(e->pipe_second_done[i]);
-  }
   for (int i = 0; i < pla_engine::kPipeTimed; ++i) {
     if (e->pipe_t0[i]) (void)hipEventDestroy(e->pipe_t0[i]);
     if (e->pipe_t1[i]) (void)hipEventDestroy(e->pipe_t1[i]);
@@ -496,20 +489,11 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
   static const bool force_transpose = getenv("PLA_INGEST_TRANSPOSE") && atoi(getenv("PLA_INGEST_TRANSPOSE")) != 0;
   constexpr int64_t kDevBlock = (int64_t)1 << 20;  // rows per launch of a device-resident matrix (bounds the hand-over buffer)
   const bool use_col = ingest && method == PLA_PSIS && !force_transpose && pla::col_supported((int)n_draws, (int)tail_count, &col_kq);
-  // Pipelined split pass (device-resident, draws-fastest matrices): blocks of kPipeBlock observations; the first kernel of
-  // block b + 1 (HBM stream, two waves per SIMD) runs beside the fit kernel of block b (fp64 issue, no HBM traffic to speak
-  // of), which is compiled to fit into the registers and LDS the first kernel leaves free on a CU.  PLA_PIPE=0: one block of
-  // up to 2^20 observations at a time, kernels back to back on the caller's stream (round 2's arrangement; A/B runs).
-  static const int64_t kPipeBlock = [] {
-    const char* e = getenv("PLA_PIPE_BLOCK");
-    const int64_t v = e ? atoll(e) : 0;
-    return v >= 1024 ? v : (int64_t)65536;
-  }();
-  static const int pipe_mode = [] {  // 0 off, 1 on (slim fit kernel), 2 on with the stand-alone fit kernel
-    const char* e = getenv("PLA_PIPE");
-    return e ? atoi(e) : 1;
-  }();
-  bool pipeline = pipe_mode != 0 && mem_space == PLA_DEVICE && !ingest && method == PLA_PSIS && n_obs >= 2 * kPipeBlock;
+  // Streamed split pass (device-resident, draws-fastest matrices): the fit kernel runs BESIDE the wave kernel, in the registers
+  // and LDS that kernel leaves free on a CU, and takes the chunks of observations as they are finished (pla_kernels.hip,
+  // launch_wave).  PLA_PIPE=0: the two kernels back to back on the caller's stream (round 2's arrangement; A/B runs).
+  const char* pipe_env = getenv("PLA_PIPE");  // (read per call: tests compare the two arrangements in one process)
+  bool pipeline = !(pipe_env && atoi(pipe_env) == 0) && mem_space == PLA_DEVICE && !ingest && method == PLA_PSIS;
 
   pla::RowsParams p{};
   p.n_obs = n_obs;
@@ -535,22 +519,25 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
         // many observations there are)
         int64_t rows = (mem_space == PLA_DEVICE && !ingest) ? (n_obs < kDevBlock ? n_obs : kDevBlock) : chunk_rows;
         const int stride = (int)((tail_count + 63) & ~(int64_t)63);  // 16 lanes x 4 values per quad
-        if (pipeline) {  // does the launcher run these rows as a split pass at all?
+        if (pipeline) {  // does the launcher stream these rows at all?
           pla::RowsParams q = p;
           q.in = ll;
           q.stride_obs = stride_obs;
           q.stride_draw = stride_draw;
-          q.n_obs = kPipeBlock;
+          q.n_obs = rows;
           q.ws_y = q.ws_s = (double*)eng->counters;  // (any non-null pointer: only looked at, never dereferenced)
           q.ws_stride = stride;
-          pipeline = pla::rows_split_planned(q, dtype);
+          q.ws_sstride = 16;
+          pipeline = pla::rows_stream_planned(q, dtype);
         }
         if (pipeline) {
           rc = ensure_pipe(eng);
           if (rc) return rc;
-          rows = kPipeBlock * pla_engine::kPipeRing;  // a ring of blocks in flight (0.44 GB at M = 190)
+          rc = grow(&eng->d_sync, &eng->d_sync_bytes, pla::stream_sync_bytes(rows));
+          if (rc) return rc;
         }
-        rc = grow(&eng->d_ws, &eng->d_ws_bytes, (size_t)rows * (size_t)(stride + 8) * sizeof(double));
+        const int sstride = pipeline ? 16 : 8;  // (streamed: one whole 128-byte line of scalars per observation)
+        rc = grow(&eng->d_ws, &eng->d_ws_bytes, (size_t)rows * (size_t)(stride + sstride) * sizeof(double));
         if (rc == PLA_ERR_NOMEM && !use_col) {
           rc = 0;  // no room for the hand-over: the fused kernels need none (the split pass is the faster, not the only, path)
         } else {
@@ -558,6 +545,7 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
           p.ws_y = (double*)eng->d_ws;
           p.ws_s = (double*)eng->d_ws + (size_t)rows * stride;
           p.ws_stride = stride;
+          p.ws_sstride = sstride;
         }
       }
     }
@@ -631,47 +619,6 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
       if (rc) return rc;
     }
     const int64_t* all_rows = p.row_index;
-    if (pipeline) {
-      constexpr int K = pla_engine::kPipeRing;
-      pla::RowsParams pa = p;  // the whole call: what the general kernel walks at the end
-      double* const ws_y0 = p.ws_y;
-      double* const ws_s0 = p.ws_s;
-      TimedLaunch t(eng, s);
-      PLA_HIP(hipEventRecord(eng->pipe_fork, s));
-      PLA_HIP(hipStreamWaitEvent(eng->pipe_first, eng->pipe_fork, 0));
-      PLA_HIP(hipStreamWaitEvent(eng->pipe_second, eng->pipe_fork, 0));
-      int64_t b = 0;
-      for (int64_t r0 = 0; r0 < n_obs; r0 += kPipeBlock, ++b) {
-        const int64_t nr = (n_obs - r0 < kPipeBlock) ? (n_obs - r0) : kPipeBlock;
-        const int slot = (int)(b % K);
-        // the hand-over slot is free once the fit kernel of block b - K has read it
-        if (b >= K) PLA_HIP(hipStreamWaitEvent(eng->pipe_first, eng->pipe_second_done[slot], 0));
-        p.n_obs = nr;
-        if (all_rows) p.row_index = all_rows + r0;
-        else p.in = (const char*)ll + (size_t)r0 * (size_t)stride_obs * esz;
-        p.diag = dd ? dd + r0 : nullptr;
-        p.loo_i = dl ? dl + r0 : nullptr;
-        p.lppd_i = dp ? dp + r0 : nullptr;
-        p.ws_y = ws_y0 + (size_t)slot * (size_t)kPipeBlock * (size_t)p.ws_stride;
-        p.ws_s = ws_s0 + (size_t)slot * (size_t)kPipeBlock * 8;
-        pla::PipeStreams ps{eng->pipe_first, eng->pipe_second, eng->pipe_first_done[slot], nullptr, pipe_mode == 1, (unsigned)r0};
-        const bool timed = eng->timing && eng->pipe_timed < pla_engine::kPipeTimed;
-        if (timed) ps.before_first = eng->pipe_t0[eng->pipe_timed];
-        PLA_HIP(pla::launch_rows(p, dtype, false, s, timed ? eng->pipe_t1[eng->pipe_timed] : nullptr, nullptr, &ps));
-        if (timed) eng->pipe_timed += 1;
-        PLA_HIP(hipEventRecord(eng->pipe_second_done[slot], eng->pipe_second));
-      }
-      PLA_HIP(hipEventRecord(eng->pipe_join1, eng->pipe_first));
-      PLA_HIP(hipEventRecord(eng->pipe_join2, eng->pipe_second));
-      PLA_HIP(hipStreamWaitEvent(s, eng->pipe_join1, 0));
-      PLA_HIP(hipStreamWaitEvent(s, eng->pipe_join2, 0));
-      // the rows the fast kernels declined, from every block (one list, global row numbers)
-      pa.ws_y = pa.ws_s = nullptr;
-      pa.diag = dd;
-      pa.loo_i = dl;
-      pa.lppd_i = dp;
-      PLA_HIP(pla::launch_slow_rows(pa, dtype, s));
-    } else
     for (int64_t r0 = 0; r0 < n_obs; r0 += kDevBlock) {
       const int64_t nr = (n_obs - r0 < kDevBlock) ? (n_obs - r0) : kDevBlock;
       p.n_obs = nr;
@@ -681,7 +628,18 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
       p.loo_i = dl ? dl + r0 : nullptr;
       p.lppd_i = dp ? dp + r0 : nullptr;
       TimedLaunch t(eng, s);
-      PLA_HIP(pla::launch_rows(p, dtype, false, s, t.mid(), t.mid_flag()));
+      if (pipeline) {
+        pla::PipeStreams ps{eng->pipe_first, eng->pipe_second, eng->pipe_fork, eng->pipe_join1, eng->pipe_join2, (unsigned*)eng->d_sync,
+                            nullptr, nullptr};
+        if (eng->timing && eng->pipe_timed < pla_engine::kPipeTimed) {
+          ps.before_first = eng->pipe_t0[eng->pipe_timed];
+          ps.after_first = eng->pipe_t1[eng->pipe_timed];
+          eng->pipe_timed += 1;
+        }
+        PLA_HIP(pla::launch_rows(p, dtype, false, s, nullptr, nullptr, &ps));
+      } else {
+        PLA_HIP(pla::launch_rows(p, dtype, false, s, t.mid(), t.mid_flag()));
+      }
     }
 #if defined(PLA_WAVE_ABLATE) && PLA_WAVE_ABLATE
     if (getenv("PLA_PRINT_REASONS")) {  // profiling build only: why rows left the fast path

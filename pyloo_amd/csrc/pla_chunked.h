@@ -240,7 +240,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
     if (slow) {
       const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
       F.slow_list[idx] = (unsigned)r + F.slow_base;
-      if constexpr (SPLIT) F.ws_s[r * 8 + 5] = -1.0;  // tail length -1: on the list, nothing for the fit kernel
+      if constexpr (SPLIT) F.ws_s[r * F.ws_sstride + 5] = -1.0;  // tail length -1: on the list, nothing for the fit kernel
     } else if constexpr (!SPLIT) {
       double *pd = P.diag, *pl = P.loo_i, *pp = P.lppd_i;
       asm volatile("" : "+s"(pd), "+s"(pl), "+s"(pp));  // (null tests inside the row loop, not hoisted into scalar registers it lacks)

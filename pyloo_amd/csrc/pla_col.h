@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kWave * 4) void col_select_kernel(ColParams P, Fast
     if (slow && lane == 0) {
       const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
       F.slow_list[idx] = (unsigned)r;
-      F.ws_s[r * 8 + 5] = -1.0;  // tail length -1: on the list, nothing for the fit kernel
+      F.ws_s[r * F.ws_sstride + 5] = -1.0;  // tail length -1: on the list, nothing for the fit kernel
     }
   }
 }

@@ -476,8 +476,9 @@ __global__ __launch_bounds__(256) void e_loo_wave_kernel(ELooParams P) {
 // descent on order-preserving 64-bit keys, 8 bits per pass, with a 256-bin LDS histogram OF WEIGHTS (ds_add_f64) -- the
 // weighted twin of the general kernel's selection (pla_rows.h) -- which also yields (b); (c) is one more pass.  Constant
 // weights take np.quantile's branch (e_loo.py:536-537): the same descent on counts, numpy's `linear` interpolation.
-// Equal draws are treated as one draw carrying their combined weight (the reference orders ties by an unstable argsort;
-// the result differs only when `prob` is crossed inside a group of equal draws with unequal weights).
+// Equal draws: the descent finds the group as a whole; inside it the reference's element-by-element walk is followed -- only
+// the group's FIRST member (here: lowest draw index; the reference: wherever its unstable argsort puts it) interpolates from
+// the value below, a target crossed at a later member returns the value itself.
 // ---------------------------------------------------------------------------------------------------------------------
 struct EQuantParams {
   const void* x;
@@ -698,6 +699,15 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
       }
     };
     const auto each_count = [&](auto f) { each([&](const uint64_t k, const double) { f(k, 1.0); }); };
+    const auto each_s = [&](auto f) {  // f(key, weight, draw index)
+      if (kept) {
+#pragma unroll
+        for (int j = 0; j < kKeep; ++j)
+          if (tid + j * BLOCK < S) f(kreg[j], wreg[j], tid + j * BLOCK);
+      } else {
+        for (int s = tid; s < S; s += BLOCK) f(key_at(s), wat(s), s);
+      }
+    };
     double wtot = 0.0;
     if (!flat) {
       each([&](const uint64_t, const double w) { wtot += w; });
@@ -736,11 +746,28 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
             if (k < kv) prev = fmax(prev, val_of(k));
           });
           prev = block_reduce<OpMax, BLOCK>(prev, red);
+          // Equal draws: the reference walks the SORTED draws one by one (542-554), so inside a group of equal draws only
+          // its first member interpolates from the value below -- with its own weight -- and a target crossed at any later
+          // member has x1 == x_sorted[wi] and returns v exactly.  (Collapsing the group into one draw of the combined weight
+          // gave 4.36 where the reference gives 5.0 on count data.)  The reference's order inside the group is that of an
+          // unstable argsort; here it is draw order: the first member is the tied draw with the lowest index.
+          double sfirst = 1e300;
+          each_s([&](const uint64_t k, const double, const int si) {
+            if (k == kv) sfirst = fmin(sfirst, (double)si);
+          });
+          sfirst = block_reduce<OpMin, BLOCK>(sfirst, red);
+          double wfirst = 0.0;
+          each_s([&](const uint64_t, const double w, const int si) {
+            if ((double)si == sfirst) wfirst = w;
+          });
+          wfirst = block_reduce<OpSum, BLOCK>(wfirst, red);
           if (below == 0.0 && prev == -pinf()) res = v;                                   // wi == 0: 548-550
+          else if (!(below + wfirst >= prob * wtot)) res = v;                             // crossed inside the group of equal draws
           else {
-            const double w1 = below / wtot, wwi = (below + at) / wtot;                    // 552
+            const double w1 = below / wtot, wwi = (below + wfirst) / wtot;                // 552
             res = prev + (v - prev) * (prob - w1) / (wwi - w1);                           // 554
           }
+          (void)at;
         }
       }
       if (tid == 0) P.out[r * P.n_probs + ip] = res;

@@ -53,6 +53,19 @@ struct FastParams {
   double* ws_s = nullptr;         // [n_obs][8] scalars
   int ws_stride = 0;
   unsigned slow_base = 0;         // added to the row numbers written to slow_list (pipelined pass: one list for all blocks)
+  // Dynamic row queue (null: row r = first + i * waves, fixed at launch): waves take chunks of kQueueChunk consecutive rows from
+  // this counter (zero at launch).  Nothing then depends on every workgroup of the grid being resident at once -- a kernel that
+  // shares the chip with another one (pipelined pass) loses the rows of a displaced workgroup to its neighbours, not its time.
+  unsigned* queue = nullptr;
+  int ws_sstride = 8;             // doubles per observation in ws_s (16 = one 128-byte line each: streamed pass)
+  // Streamed split pass (pla_fit.h, fit_rows_stream_kernel): the fit kernel runs BESIDE this kernel and takes the chunks of
+  // kQueueChunk rows as they are finished: done[c] is set (agent scope) once every hand-over store of chunk c has drained.
+  unsigned* done = nullptr;
+  int prio = 0;                   // s_setprio of the wave kernel's waves (streamed pass: the fit kernel beside it takes what is left)
 };
+#ifndef PLA_QUEUE_CHUNK
+#define PLA_QUEUE_CHUNK 16
+#endif
+constexpr int kQueueChunk = PLA_QUEUE_CHUNK;
 
 }  // namespace pla

@@ -42,6 +42,9 @@ constexpr int kFitCoefStride = 6;  // (VALU grid pass) doubles per quad in LDS, 
 #ifndef PLA_FIT_MIN_WAVES
 #define PLA_FIT_MIN_WAVES 2  // waves per SIMD the fit kernel is compiled for
 #endif
+#ifndef PLA_STREAM_SLEEP
+#define PLA_STREAM_SLEEP 32  // s_sleep argument between two looks at a chunk's flag (units of 64 cycles)
+#endif
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 struct FitParams {
@@ -62,7 +65,32 @@ struct FitParams {
   unsigned* slow_list;
   unsigned long long* counters;
   unsigned slow_base = 0;  // added to the row numbers written to slow_list
+  int ws_sstride = 8;      // doubles per observation in ws_s
+  // streamed pass (fit_rows_stream_kernel): chunks of kQueueChunk observations are taken from `take` in order, each once
+  // `done[c]` is set by the wave kernel running beside this one; `fitted[c]` is set behind the chunk's outputs.  Polling gives
+  // up after `patience` looks (the two kernels were not run side by side after all): `gave_up` is then set and the chunks not
+  // fitted are left to the plain fit kernel, which the launcher always runs behind both (fit_rows_kernel with `fitted`: it only
+  // looks at chunks whose flag is clear, i.e. at nothing in the usual case).
+  const unsigned* done = nullptr;
+  unsigned* take = nullptr;
+  unsigned* fitted = nullptr;
+  unsigned* gave_up = nullptr;
+  unsigned patience = 0;
 };
+
+// 16 bytes of the hand-over.  STREAM: an agent-scope (sc1) load straight from memory -- the bytes were written, by the kernel
+// running beside this one, after this kernel started (no kernel boundary in between: see FastParams::done)
+template <bool STREAM>
+__device__ __forceinline__ double2 ws_load2(const double* base, const int64_t elem) {
+  if constexpr (STREAM) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, 0x7fffffff, 0x00020000);
+    const v4i t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(elem * 8), 0, 16);  // aux 16 = sc1
+    return make_double2(__hiloint2double(t[1], t[0]), __hiloint2double(t[3], t[2]));
+  } else {
+    return *reinterpret_cast<const double2*>(base + elem);
+  }
+}
 
 // reduction over the 16 lanes of a DPP row; every lane of the row ends up with the (bitwise identical) result
 template <class F>
@@ -86,8 +114,10 @@ __device__ __forceinline__ int row_all_add(int v) {
 // kernel at three waves per SIMD and holds the register budget its launch bounds ask for instead of relaxing it to that cap.
 template <int NQ, int W>
 constexpr size_t fit_coef_bytes() { return (size_t)W * 5 * 4 * (16 * NQ) * sizeof(double); }
-template <int NQ, int G, int W, bool DYN = false>
+template <int NQ, int G, int W, bool DYN = false, bool STREAM = false>
 __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
+  static_assert(!STREAM || W * 4 == kQueueChunk, "streamed pass: one chunk of the wave kernel per workgroup and trip");
+  __shared__ int s_chunk;
   constexpr int kFitWaves = W;  // (shadows the default: everything below is per instantiation)
   __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];
   __shared__ __attribute__((aligned(16))) double lt[2 * kLogTabN];
@@ -156,7 +186,44 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
   const double g_first = Q.b_grid[0], g_last = Q.b_grid[mestM - 1];
   const int64_t ngroups = (Q.n_obs + 3) >> 2;
   const int t_lane = t;
-  for (int64_t grp = (int64_t)blockIdx.x * kFitWaves + wv; grp < ngroups; grp += (int64_t)gridDim.x * kFitWaves) {
+  const int64_t nchunks = (Q.n_obs + kQueueChunk - 1) / kQueueChunk;
+  int64_t grp = (int64_t)blockIdx.x * kFitWaves + wv;
+  int prev_chunk = -1;
+  for (;; grp += (int64_t)gridDim.x * kFitWaves) {
+    if constexpr (STREAM) {
+      // the next chunk in order, once the wave kernel has finished it: one lane takes it and polls (agent-scope loads, a
+      // sleep in between); the workgroup barrier stands between that poll and every load of the chunk's bytes
+      __syncthreads();  // (everybody is done with s_chunk, and with the chunk, of the previous trip)
+      if (tid == 0) {
+        if (prev_chunk >= 0) Q.fitted[prev_chunk] = 1u;
+        int c = (int)atomicAdd(Q.take, 1u);
+        if ((int64_t)c < nchunks) {
+          unsigned looks = 0;
+          while (__hip_atomic_load(Q.done + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            if (++looks > Q.patience) {
+              __hip_atomic_store(Q.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              c = -1;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(PLA_STREAM_SLEEP);
+          }
+        } else {
+          c = -1;
+        }
+        s_chunk = c;
+      }
+      __syncthreads();
+      const int c = s_chunk;
+      prev_chunk = c;
+      if (c < 0) break;
+      grp = (int64_t)c * (kQueueChunk / 4) + wv;
+      if (grp >= ngroups) continue;  // (the last chunk may be short)
+    } else {
+      if (grp >= ngroups) break;
+      if (Q.fitted) {  // behind a streamed pass: only what that pass left (nothing, unless it gave up waiting)
+        if (Q.fitted[grp / (kQueueChunk / 4)] != 0u) continue;
+      }
+    }
     // (opaque per group: the ranks, table offsets and LDS addresses derived from the lane number are then computed where they
     // are used instead of being hoisted above the loop, where a dozen of them sit on the register budget of the slim variant)
     int t = t_lane;
@@ -164,18 +231,18 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     const int64_t r0 = grp * 4 + rho;
     const bool inrange = r0 < Q.n_obs;
     const int64_t r = inrange ? r0 : Q.n_obs - 1;
-    const double* sc = Q.ws_s + r * 8;
-    const double2 sc01 = *reinterpret_cast<const double2*>(sc), sc23 = *reinterpret_cast<const double2*>(sc + 2),
-                  sc45 = *reinterpret_cast<const double2*>(sc + 4);
+    const int64_t sc = r * Q.ws_sstride;
+    const double2 sc01 = ws_load2<STREAM>(Q.ws_s, sc), sc23 = ws_load2<STREAM>(Q.ws_s, sc + 2), sc45 = ws_load2<STREAM>(Q.ws_s, sc + 4);
     const double m = sc01.x, mn = sc01.y, s1 = sc23.x, s2 = sc23.y, e_cut = sc45.x;
     const int nraw = (int)sc45.y;
     const bool handled = inrange && nraw >= 0;  // (else: past the end, or declined by the wave kernel and already listed)
     const int n = nraw < 0 ? 0 : (nraw > M ? M : nraw);
     const bool fit = n > 4;  // psis.py:139: shorter tails are neither fitted nor smoothed (their y was not written)
-    const double* y = Q.ws_y + r * (int64_t)Q.ws_stride;
+    const int64_t y0 = r * (int64_t)Q.ws_stride;
+    const double* y = Q.ws_y + y0;
     double2 yv[2 * NQ];  // element j = 32 i + 2 t + {0, 1}
 #pragma unroll
-    for (int i = 0; i < 2 * NQ; ++i) yv[i] = *reinterpret_cast<const double2*>(y + 32 * i + 2 * t);
+    for (int i = 0; i < 2 * NQ; ++i) yv[i] = ws_load2<STREAM>(Q.ws_y, y0 + 32 * i + 2 * t);
     const int iq = ((n + 2) >> 2) - 1;
     double yq, yn;
     if constexpr (kFitSorts) {
@@ -478,15 +545,21 @@ __global__ __launch_bounds__(kWave * W, PLA_FIT_MIN_WAVES) void fit_rows_kernel(
   fit_rows_body<NQ, G, W>(Q);
 }
 
-// The same fit for the pipelined pass (pla_capi.hip): it runs BESIDE the wave kernel of the next block of observations, in
-// what that kernel leaves free on a CU -- 512 - 2 x 192 = 128 vector registers per SIMD and 160 KB - 2 x 66 KB of LDS -- so it
-// is compiled for at most 128 registers and two waves per workgroup (half the coefficient scratch: 25 KB of LDS in all).
+// The same fit for the streamed pass (pla_kernels.hip, launch_wave): it runs BESIDE the wave kernel, in what two workgroups of
+// that kernel leave free on a CU -- 512 - 2 x 192 = 128 vector registers per SIMD and 160 KB - 2 x 58 KB of LDS -- so it is
+// compiled for at most 128 registers (four waves per workgroup, 39.5 KB of LDS: one workgroup per CU beside the wave kernel's
+// two).  fit_rows_stream_kernel takes the chunks as the wave kernel finishes them; fit_rows_slim_kernel walks its groups in a
+// fixed order (experiments).
 #ifndef PLA_FIT_SLIM_WAVES
 #define PLA_FIT_SLIM_WAVES 4  // waves per SIMD the register budget is derived from: 4 -> 128 registers (5 -> 96: spills)
 #endif
 template <int NQ, int G = 3, int W = 2>
 __global__ __launch_bounds__(kWave * W, PLA_FIT_SLIM_WAVES) void fit_rows_slim_kernel(FitParams Q) {
   fit_rows_body<NQ, G, W, true>(Q);
+}
+template <int NQ, int G = 3>
+__global__ __launch_bounds__(kWave * 4, PLA_FIT_SLIM_WAVES) void fit_rows_stream_kernel(FitParams Q) {
+  fit_rows_body<NQ, G, 4, true, true>(Q);
 }
 
 }  // namespace pla

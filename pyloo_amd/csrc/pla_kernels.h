@@ -30,23 +30,22 @@ struct RowsParams {
   // optional row selection (loo_subsample, loo_subsample.py:316-330): observation r of this call is row row_index[r] of `in`;
   // outputs stay compact ([n_obs] = number of selected rows)
   const int64_t* row_index = nullptr;  // (already clamped into the matrix: launch_clamp_rows)
-  unsigned long long* slow_total = nullptr;  // running total of rows left to the general kernel (null: counters + 1)
+  int ws_sstride = 8;            // doubles per observation in ws_s (16 in the streamed pass: one 128-byte line each)
 };
 
-// Pipelined split pass (pla_capi.hip): the first kernel of a block of observations (statistics, sweep, selection) runs on
-// `first`, its fit kernel and the general kernel over the declined rows on `second` behind `first_done` -- beside the first
-// kernel of the NEXT block.  The caller forks both streams from, and joins them to, its own.
+// Streamed split pass: the first kernel (statistics, sweep, selection; HBM stream) on `first` and, BESIDE it on `second`, the
+// fit kernel, which takes the chunks of observations as the first kernel finishes them (FastParams::done, pla_fit.h).  Both
+// streams are forked from and joined to the caller's inside launch_rows(); `sync` is device memory for the flags and queues of
+// one launch (stream_sync_bytes(n_obs)), zeroed by the launcher.
 struct PipeStreams {
   hipStream_t first;
   hipStream_t second;
-  hipEvent_t first_done;    // recorded on `first` behind the first kernel
-  hipEvent_t before_first;  // optional (timing): recorded on `first` right before the first kernel
-  bool slim_fit;            // fit kernel compiled for the registers / LDS the first kernel leaves free on a CU
-  // One slow list and one counter for all blocks: the kernels add `slow_base` (the block's first row) to the rows they list,
-  // nothing resets the counter and the general kernel is NOT launched per block -- the caller runs launch_slow_rows() once
-  // over the whole matrix behind the join.
-  unsigned slow_base;
+  hipEvent_t fork, join_first, join_second;  // (timing disabled)
+  unsigned* sync;
+  hipEvent_t before_first;  // optional (timing): recorded on `first` right before the first kernel ...
+  hipEvent_t after_first;   // ... and right behind it
 };
+size_t stream_sync_bytes(int64_t n_obs);
 
 // element offset of observation r's row in the input matrix
 #define PLA_ROW_OFFSET(P, r) (((P).row_index ? (P).row_index[(r)] : (int64_t)(r)) * (P).stride_obs)
@@ -67,9 +66,8 @@ struct ReduceParams {
 hipError_t launch_rows(const RowsParams& p, int dtype, bool lw_mode, hipStream_t stream, hipEvent_t after_first = nullptr,
                        bool* recorded = nullptr, const PipeStreams* pipe = nullptr);
 // true when launch_rows() would run these rows as a split pass (first kernel + fit kernel): the shapes the pipeline serves
-bool rows_split_planned(const RowsParams& p, int dtype);
-// general kernel over the rows on p.slow_list (p.counters[0] of them): the tail of a pipelined pass
-hipError_t launch_slow_rows(const RowsParams& p, int dtype, hipStream_t stream);
+// true when launch_rows() given a PipeStreams would run these rows as a streamed split pass
+bool rows_stream_planned(const RowsParams& p, int dtype);
 hipError_t launch_reduce(const ReduceParams& p, double* workspace, hipStream_t stream);
 // out[i] = min(max(in[i], 0), n_src - 1): a caller's device index list can never make a row kernel read outside the matrix
 hipError_t launch_clamp_rows(const int64_t* in, int64_t n_rows, int64_t n_src, int64_t* out, hipStream_t stream);

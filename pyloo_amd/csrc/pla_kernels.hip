@@ -53,7 +53,7 @@ __global__ __launch_bounds__(BLOCK) void slow_rows_kernel(RowsParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const Smem sm = carve<BLOCK>(smem_raw, P.tail_cap);
   const unsigned long long count = P.counters[0];
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(P.slow_total ? P.slow_total : &P.counters[1], count);  // running total of this call
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&P.counters[1], count);  // running total of this call
   for (unsigned long long i = blockIdx.x; i < count; i += gridDim.x) {
     const int64_t r = (int64_t)P.slow_list[i];
     const T* rp = reinterpret_cast<const T*>(P.in) + PLA_ROW_OFFSET(P, r);
@@ -248,6 +248,8 @@ static int debug_flag(const char* name) {
 // short-lived waves pay that start-up again and again), at most 8 rounds (many rounds even out clock and memory-channel luck)
 static int64_t wave_grid(int64_t n_obs, int waves) {
   const int64_t need = (n_obs + waves - 1) / waves;
+  static const int forced = debug_flag("PLA_WAVE_GRID");  // experiments
+  if (forced > 0) return forced < need ? forced : need;
   if (need <= 512) return need < 1 ? 1 : need;
   int64_t grid = 512;
   while (grid < 4096 && n_obs / (2 * grid * waves) >= 24) grid *= 2;
@@ -255,24 +257,15 @@ static int64_t wave_grid(int64_t n_obs, int waves) {
 }
 
 // second kernel of a split LOO pass: fit / smoothing / outputs for the tails the selection kernel handed over (pla_fit.h)
-static hipError_t launch_fit(const RowsParams& p, const FastParams& f, int mestM, hipStream_t stream, bool slim = false) {
+static hipError_t launch_fit(const RowsParams& p, const FastParams& f, int mestM, hipStream_t stream, const unsigned* fitted = nullptr) {
   FitParams q{p.ws_y, p.ws_s, p.ws_stride, p.n_obs, p.n_draws, p.tail_count, mestM, f.log_S, p.scale_value, p.l1_table,
               p.l1_table + p.tail_count, p.diag, p.loo_i, p.lppd_i, p.slow_list, p.counters};
   q.slow_base = f.slow_base;
+  q.ws_sstride = f.ws_sstride;
+  q.fitted = const_cast<unsigned*>(fitted);  // (behind a streamed pass: only the chunks that pass left)
+  static const int skip_fit = debug_flag("PLA_SKIP_FIT");  // timing experiments only: the outputs are then garbage
+  if (skip_fit) return hipSuccess;
   const int nq = p.ws_stride / 64;
-  if (slim && nq <= 4) {
-    // pipelined pass: one two-wave workgroup per CU fits beside the wave kernel's two; every wave walks many groups
-    int64_t g = ((p.n_obs + 3) / 4 + 1) / 2;
-    if (g > 256 * 4) g = 256 * 4;
-    const dim3 sg((unsigned)g), sb(kWave * 2);
-    switch (nq) {  // (the coefficient scratch is dynamic LDS: pla_fit.h, DYN)
-      case 1: hipLaunchKernelGGL(fit_rows_slim_kernel<1>, sg, sb, (fit_coef_bytes<1, 2>()), stream, q); break;
-      case 2: hipLaunchKernelGGL(fit_rows_slim_kernel<2>, sg, sb, (fit_coef_bytes<2, 2>()), stream, q); break;
-      case 3: hipLaunchKernelGGL(fit_rows_slim_kernel<3>, sg, sb, (fit_coef_bytes<3, 2>()), stream, q); break;
-      default: hipLaunchKernelGGL(fit_rows_slim_kernel<4>, sg, sb, (fit_coef_bytes<4, 2>()), stream, q); break;
-    }
-    return hipGetLastError();
-  }
   const int waves = nq <= 4 ? kFitWaves : 2;
   int64_t g3 = ((p.n_obs + 3) / 4 + waves - 1) / waves;  // four observations per wave
   if (g3 > 256 * 8) g3 = 256 * 8;
@@ -288,6 +281,37 @@ static hipError_t launch_fit(const RowsParams& p, const FastParams& f, int mestM
   }
   return hipGetLastError();
 }
+// Streamed pass, the fit kernel that runs beside the wave kernel: ONE four-wave workgroup per CU is what fits there (128
+// registers per lane, 39.5 KB of LDS next to two workgroups of the wave kernel), and the workgroups stay for the whole launch
+static hipError_t launch_fit_stream(const RowsParams& p, const FastParams& f, int mestM, unsigned* sync, hipStream_t stream) {
+  FitParams q{p.ws_y, p.ws_s, p.ws_stride, p.n_obs, p.n_draws, p.tail_count, mestM, f.log_S, p.scale_value, p.l1_table,
+              p.l1_table + p.tail_count, p.diag, p.loo_i, p.lppd_i, p.slow_list, p.counters};
+  q.slow_base = f.slow_base;
+  q.ws_sstride = f.ws_sstride;
+  const int64_t nchunks = (p.n_obs + kQueueChunk - 1) / kQueueChunk;
+  q.take = sync + 16;
+  q.gave_up = sync + 32;
+  q.done = sync + 48;
+  q.fitted = sync + 48 + nchunks;
+  // polls are ~0.3 us apart (s_sleep 32 + one load): two seconds of them, then the chunk is left to the plain fit kernel
+  static const int patience = debug_flag("PLA_STREAM_PATIENCE");
+  q.patience = patience > 0 ? (unsigned)patience : 6000000u;
+  static const int fg_forced = debug_flag("PLA_FIT_GRID");
+  int64_t g = nchunks < 256 ? nchunks : 256;
+  if (fg_forced > 0 && fg_forced < nchunks) g = fg_forced;
+  const dim3 sg((unsigned)g), sb(kWave * 4);
+  switch (p.ws_stride / 64) {  // (the coefficient scratch is dynamic LDS: pla_fit.h, DYN)
+    case 1: hipLaunchKernelGGL(fit_rows_stream_kernel<1>, sg, sb, (fit_coef_bytes<1, 4>()), stream, q); break;
+    case 2: hipLaunchKernelGGL(fit_rows_stream_kernel<2>, sg, sb, (fit_coef_bytes<2, 4>()), stream, q); break;
+    case 3: hipLaunchKernelGGL(fit_rows_stream_kernel<3>, sg, sb, (fit_coef_bytes<3, 4>()), stream, q); break;
+    default: hipLaunchKernelGGL(fit_rows_stream_kernel<4>, sg, sb, (fit_coef_bytes<4, 4>()), stream, q); break;
+  }
+  return hipGetLastError();
+}
+size_t stream_sync_bytes(int64_t n_obs) {
+  const int64_t nchunks = (n_obs + kQueueChunk - 1) / kQueueChunk;
+  return (size_t)(48 + 2 * nchunks + 16) * sizeof(unsigned);
+}
 // shapes the split pass covers: hand-over buffers present, tail within the stride, grid within the fit kernel's lanes
 static bool split_ok(const RowsParams& p, int mestM) {
   if (!p.ws_y || !p.ws_s || p.ws_stride % 64 != 0 || p.tail_count > p.ws_stride) return false;
@@ -295,9 +319,8 @@ static bool split_ok(const RowsParams& p, int mestM) {
 }
 
 template <typename T, int VEC, bool LW>
-static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, const ThresholdCheck& chk, hipStream_t stream_in,
-                              hipEvent_t after_first, bool* recorded, const PipeStreams* pipe, int* plan) {
-  hipStream_t stream = pipe ? pipe->first : stream_in;
+static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, const ThresholdCheck& chk, hipStream_t stream,
+                              hipEvent_t after_first, bool* recorded, const PipeStreams* pipe, int* plan_stream) {
   hipError_t e = hipSuccess;
   static const int dbg = debug_flag("PLA_DEBUG_SKIP");
   static const int fused = debug_flag("PLA_FUSED");  // 1: single fused kernel (the pre-split pass), for A/B runs
@@ -312,37 +335,70 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, co
   // 256 CUs (8 waves each) busy with a short tail
   const int64_t grid = wave_grid(p.n_obs, kWavesPerBlock);
   const bool split = !LW && !fused && !(dbg & 31) && p.ws_stride <= 256 && split_ok(p, mestM);  // (ablation bits >= 32 live inside the split pass)
-  if (plan) {
-    *plan = split ? 1 : 0;
+  const bool streamed = pipe && split && pipe->sync && p.ws_sstride == 16 && p.n_obs < ((int64_t)1 << 31);
+  if (plan_stream) {
+    *plan_stream = streamed ? 1 : 0;
     return hipSuccess;
   }
-  if (!(pipe && split)) {  // (pipelined split pass: one counter for all blocks, reset by the caller)
-    e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
-    if (e != hipSuccess) return e;
-  }
+  e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return e;
   if constexpr (!LW) {
     if (split) {
-      if (pipe) f.slow_base = pipe->slow_base;
       // split pass: wave kernel up to the exact selection, then sixteen lanes per observation for the GPD fit,
       // the smoothing sums and the outputs (pla_fit.h)
       f.ws_y = p.ws_y;
       f.ws_s = p.ws_s;
       f.ws_stride = p.ws_stride;
-      if (pipe && pipe->before_first) (void)hipEventRecord(pipe->before_first, stream);
-      hipLaunchKernelGGL((wave_loo_kernel<T, VEC, false, CapsSmall, true>), dim3((unsigned)grid), dim3(kWave * kWavesPerBlock), 0,
-                         stream, p, f);
-      e = hipGetLastError();
-      if (e != hipSuccess) return e;
-      if (after_first && hipEventRecord(after_first, stream) == hipSuccess && recorded) *recorded = true;
-      if (pipe) {  // the fit and the general kernel run on the second stream, beside the next block's first kernel
-        e = hipEventRecord(pipe->first_done, stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(pipe->second, pipe->first_done, 0);
+      f.ws_sstride = p.ws_sstride;
+      if (streamed) {
+        // streamed: the fit kernel runs beside the wave kernel and takes the chunks as they are finished
+        unsigned* const sync = pipe->sync;
+        const int64_t nchunks = (p.n_obs + kQueueChunk - 1) / kQueueChunk;
+        e = hipMemsetAsync(sync, 0, stream_sync_bytes(p.n_obs), stream);
+        if (e == hipSuccess) e = hipEventRecord(pipe->fork, stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(pipe->first, pipe->fork, 0);
+        if (e == hipSuccess) e = hipStreamWaitEvent(pipe->second, pipe->fork, 0);
         if (e != hipSuccess) return e;
-        stream = pipe->second;
+        f.queue = sync;
+        f.done = sync + 48;
+        // the wave kernel's waves issue first (s_setprio 3: A/B on C3 6.55 ms against 7.15 at equal priority); the fit kernel
+        // fills what they leave and still ends with them (one workgroup per CU is ~70 % busy)
+        static const char* wprio = getenv("PLA_WAVE_PRIO");
+        f.prio = wprio ? atoi(wprio) : 3;
+        const int64_t need = (p.n_obs + kWavesPerBlock * kQueueChunk - 1) / (kWavesPerBlock * kQueueChunk);
+        const int64_t g1 = need < 512 ? need : 512;  // two resident workgroups per CU take everything there is from the queue
+        if (pipe->before_first) (void)hipEventRecord(pipe->before_first, pipe->first);
+        hipLaunchKernelGGL((wave_loo_kernel<T, VEC, false, CapsSmall, true, true>), dim3((unsigned)g1), dim3(kWave * kWavesPerBlock), 0,
+                           pipe->first, p, f);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (pipe->after_first) (void)hipEventRecord(pipe->after_first, pipe->first);
+        e = launch_fit_stream(p, f, mestM, sync, pipe->second);
+        if (e == hipSuccess) e = hipEventRecord(pipe->join_first, pipe->first);
+        if (e == hipSuccess) e = hipEventRecord(pipe->join_second, pipe->second);
+        if (e == hipSuccess) e = hipStreamWaitEvent(stream, pipe->join_first, 0);
+        if (e == hipSuccess) e = hipStreamWaitEvent(stream, pipe->join_second, 0);
+        if (e != hipSuccess) return e;
+        // whatever the streamed fit left (nothing, unless it gave up waiting for the wave kernel)
+        e = launch_fit(p, f, mestM, stream, sync + 48 + nchunks);
+        if (e != hipSuccess) return e;
+      } else {
+        static const int queue_too = debug_flag("PLA_QUEUE");  // A/B: dynamic row queue without the streamed fit
+        int64_t g1 = grid;
+        if (queue_too && pipe && pipe->sync) {
+          e = hipMemsetAsync(pipe->sync, 0, 64, stream);
+          if (e != hipSuccess) return e;
+          f.queue = pipe->sync;
+          g1 = g1 < 512 ? g1 : 512;
+        }
+        hipLaunchKernelGGL((wave_loo_kernel<T, VEC, false, CapsSmall, true>), dim3((unsigned)g1), dim3(kWave * kWavesPerBlock), 0,
+                           stream, p, f);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (after_first && hipEventRecord(after_first, stream) == hipSuccess && recorded) *recorded = true;
+        e = launch_fit(p, f, mestM, stream);
+        if (e != hipSuccess) return e;
       }
-      e = launch_fit(p, f, mestM, stream, pipe && pipe->slim_fit);
-      if (e != hipSuccess) return e;
-      if (pipe) return hipSuccess;  // (the general kernel runs once, behind the last block)
     }
   }
   if (!split) {
@@ -360,9 +416,8 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, co
 
 // long rows (chunks of 4096 draws) and / or tail counts up to 512: pla_chunked.h
 template <typename T, int VEC, class CAP, bool LW = false>
-static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, int bits, const ThresholdCheck& chk, hipStream_t stream_in,
-                                 hipEvent_t after_first, bool* recorded, const PipeStreams* pipe, int* plan) {
-  hipStream_t stream = pipe ? pipe->first : stream_in;
+static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, int bits, const ThresholdCheck& chk, hipStream_t stream,
+                                 hipEvent_t after_first, bool* recorded) {
   hipError_t e = hipSuccess;
   static const int fused = debug_flag("PLA_FUSED");
   int root_ = (int)std::sqrt((double)p.tail_count);
@@ -377,34 +432,19 @@ static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, int bits,
   if (grid > 2048 * 8 / W) grid = 2048 * 8 / W;
   bool split = false;
   if constexpr (CAP::kMaxTail <= 448 && !LW) split = !fused && split_ok(p, mestM) && p.ws_stride <= 64 * ((CAP::kMaxTail + 63) / 64);
-  if (plan) {
-    *plan = split ? 1 : 0;
-    return hipSuccess;
-  }
-  if (!(pipe && split)) {
-    e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
-    if (e != hipSuccess) return e;
-  }
+  e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return e;
   if (split) {
     if constexpr (CAP::kMaxTail <= 448 && !LW) {
-      if (pipe) f.slow_base = pipe->slow_base;
       f.ws_y = p.ws_y;
       f.ws_s = p.ws_s;
       f.ws_stride = p.ws_stride;
-      if (pipe && pipe->before_first) (void)hipEventRecord(pipe->before_first, stream);
       hipLaunchKernelGGL((wave_loo_chunked_kernel<T, VEC, CAP, true>), dim3((unsigned)grid), dim3(kWave * W), 0, stream, p, f);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
       if (after_first && hipEventRecord(after_first, stream) == hipSuccess && recorded) *recorded = true;
-      if (pipe) {
-        e = hipEventRecord(pipe->first_done, stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(pipe->second, pipe->first_done, 0);
-        if (e != hipSuccess) return e;
-        stream = pipe->second;
-      }
-      e = launch_fit(p, f, mestM, stream, pipe && pipe->slim_fit);
+      e = launch_fit(p, f, mestM, stream);
       if (e != hipSuccess) return e;
-      if (pipe) return hipSuccess;
     }
   } else {
     hipLaunchKernelGGL((wave_loo_chunked_kernel<T, VEC, CAP, false, LW>), dim3((unsigned)grid), dim3(kWave * W), 0, stream, p, f);
@@ -467,7 +507,7 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream, hipEvent
     }
     if (path != 1 && unit && waligned && (p.method == PLA_SIS || p.method == PLA_TIS) && p.slow_list && p.counters &&
         p.n_draws <= kWave * kWaveSlots && p.n_draws >= kWave * WVEC && p.n_obs <= 0xffffffffll)
-      return plan ? hipSuccess : launch_is<T, WVEC, LW>(p, pipe ? pipe->first : stream);
+      return plan ? hipSuccess : launch_is<T, WVEC, LW>(p, stream);
     {
       // rows beyond one register chunk or tails beyond the small kernel's LDS: the chunked kernel
       // (weights mode: the candidates carry 16-bit draw indices, so rows up to 65 536 draws; two LDS capacities)
@@ -481,21 +521,20 @@ static hipError_t launch_typed(const RowsParams& p, hipStream_t stream, hipEvent
           // (f32 rows: six waves per CU; f64 rows need more than 256 registers per lane next to the row, so four)
           using CapLW = std::conditional_t<sizeof(T) == 4, CapsMidLW, CapsMid>;
           if (p.tail_count <= CapLW::kMaxTail && wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk, CapLW::kCand))
-            return launch_chunked<T, WVEC, CapLW, true>(p, gsz, kq, bits, chk, stream, after_first, recorded, pipe, plan);
+            return plan ? hipSuccess : launch_chunked<T, WVEC, CapLW, true>(p, gsz, kq, bits, chk, stream, after_first, recorded);
           if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk, CapsBig::kCand))
-            return launch_chunked<T, WVEC, CapsBig, true>(p, gsz, kq, bits, chk, stream, after_first, recorded, pipe, plan);
+            return plan ? hipSuccess : launch_chunked<T, WVEC, CapsBig, true>(p, gsz, kq, bits, chk, stream, after_first, recorded);
         } else {
         if (p.tail_count <= CapsMid4::kMaxTail && wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk, CapsMid4::kCand))
-          return launch_chunked<T, WVEC, CapsMid4>(p, gsz, kq, bits, chk, stream, after_first, recorded, pipe, plan);
+          return plan ? hipSuccess : launch_chunked<T, WVEC, CapsMid4>(p, gsz, kq, bits, chk, stream, after_first, recorded);
         if (p.tail_count <= CapsMid::kMaxTail && wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk, CapsMid::kCand))
-          return launch_chunked<T, WVEC, CapsMid>(p, gsz, kq, bits, chk, stream, after_first, recorded, pipe, plan);
+          return plan ? hipSuccess : launch_chunked<T, WVEC, CapsMid>(p, gsz, kq, bits, chk, stream, after_first, recorded);
         if (wave_threshold_params(p.n_draws, WVEC, p.tail_count, &gsz, &kq, &bits, &chk, CapsBig::kCand))
-          return launch_chunked<T, WVEC, CapsBig>(p, gsz, kq, bits, chk, stream, after_first, recorded, pipe, plan);
+          return plan ? hipSuccess : launch_chunked<T, WVEC, CapsBig>(p, gsz, kq, bits, chk, stream, after_first, recorded);
         }
       }
     }
     if (plan) return hipSuccess;
-    if (pipe) stream = pipe->first;
     if (path == 1) return launch_one<T, BLOCK, 0, LW>(p, stream);
   }
   if (unit && p.n_draws <= BLOCK * 16 && p.n_draws > BLOCK * 4) return launch_one<T, BLOCK, 16, LW>(p, stream);
@@ -510,28 +549,13 @@ hipError_t launch_rows(const RowsParams& p, int dtype, bool lw_mode, hipStream_t
   return lw_mode ? launch_typed<float, true>(p, stream, after_first, recorded, pipe) : launch_typed<float, false>(p, stream, after_first, recorded, pipe);
 }
 
-template <typename T>
-static hipError_t launch_slow_typed(const RowsParams& p, hipStream_t stream) {
-  int64_t g2 = p.n_obs < 1024 ? p.n_obs : 1024;
-  if (p.n_draws >= 8192) {  // (long rows: the latency of one workgroup walking one row, see launch_chunked)
-    constexpr int BLOCK = 1024;
-    hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK, false>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap), stream, p);
-  } else {
-    constexpr int BLOCK = 256;
-    hipLaunchKernelGGL((slow_rows_kernel<T, BLOCK, false>), dim3((unsigned)g2), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap), stream, p);
-  }
-  return hipGetLastError();
-}
-hipError_t launch_slow_rows(const RowsParams& p, int dtype, hipStream_t stream) {
-  if (p.n_obs <= 0) return hipSuccess;
-  return dtype == PLA_F64 ? launch_slow_typed<double>(p, stream) : launch_slow_typed<float>(p, stream);
-}
-
-bool rows_split_planned(const RowsParams& p, int dtype) {
+bool rows_stream_planned(const RowsParams& p, int dtype) {
   if (p.n_obs <= 0) return false;
   int plan = 0;
-  if (dtype == PLA_F64) (void)launch_typed<double, false>(p, nullptr, nullptr, nullptr, nullptr, &plan);
-  else (void)launch_typed<float, false>(p, nullptr, nullptr, nullptr, nullptr, &plan);
+  PipeStreams probe{};
+  probe.sync = reinterpret_cast<unsigned*>(p.counters);  // (any non-null pointer: looked at, not dereferenced)
+  if (dtype == PLA_F64) (void)launch_typed<double, false>(p, nullptr, nullptr, nullptr, &probe, &plan);
+  else (void)launch_typed<float, false>(p, nullptr, nullptr, nullptr, &probe, &plan);
   return plan != 0;
 }
 

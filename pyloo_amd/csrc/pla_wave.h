@@ -1017,7 +1017,26 @@ struct CandInLds {
   __device__ __forceinline__ double* dump_slot(int lane) const { return &sm.cand[SM::Caps::kCand + kWave + lane]; }
 };
 
-template <typename SM, typename TB, int HU = 4, class SRC = CandInLds<SM>>  // HU: 64-value blocks of the hand-over (ws_stride <= 64 HU)
+// hand-over stores.  SYNC (streamed pass): agent-scope (sc1, write-through) stores, each 128-byte line written whole by one
+// instruction of this wave -- the form the fit kernel running beside this one may read behind the chunk's flag with sc1 loads
+// (MI355X_MICROARCH.md, inter-workgroup visibility)
+template <bool SYNC>
+__device__ __forceinline__ void ws_store(double* p, double v) {
+  if constexpr (SYNC) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+// the observation's scalars: lanes 0 .. sstride-1 write one entry each (one instruction; a whole line when sstride = 16)
+template <bool SYNC>
+__device__ __forceinline__ void ws_store_scalars(const FastParams& F, const int64_t r, const int lane, const double m, const double mn,
+                                                 const double s1, const double s2, const double e_cut, const double n) {
+  const int ss = F.ws_sstride;
+  if (lane < ss) {
+    const double v = lane == 0 ? m : (lane == 1 ? mn : (lane == 2 ? s1 : (lane == 3 ? s2 : (lane == 4 ? e_cut : (lane == 5 ? n : 0.0)))));
+    ws_store<SYNC>(F.ws_s + r * ss + lane, v);
+  }
+}
+
+template <typename SM, typename TB, int HU = 4, class SRC = CandInLds<SM>, bool SYNC = false>  // HU: 64-value blocks of the hand-over (ws_stride <= 64 HU)
 __device__ __forceinline__ void wave_select_split(const FastParams& F, SM& sm, const TB& tb, const int64_t r, const int lane_id,
                                                   const int M, const double m, const double mn, const double s1, const double s2,
                                                   const unsigned ncand, const int k1, const int sh, const double magic,
@@ -1047,10 +1066,7 @@ __device__ __forceinline__ void wave_select_split(const FastParams& F, SM& sm, c
   wave_all2<R_SUM>(s1, s2, s1_all, s2_all);  // (independent of the list: runs while the reads are in flight)
   const auto ablate_exit = [&](int bit) {  // profiling builds: stop here, leave a tail of length 0 (not fitted)
     if (!(dbgs & bit)) return false;
-    if (lane == 0) {
-      double* ws = F.ws_s + r * 8;
-      ws[0] = m; ws[1] = mn; ws[2] = s1_all; ws[3] = s2_all; ws[4] = 0.5; ws[5] = 0.0;
-    }
+    ws_store_scalars<SYNC>(F, r, lane, m, mn, s1_all, s2_all, 0.5, 0.0);
     return true;
   };
   if (ablate_exit(32)) return;
@@ -1143,13 +1159,6 @@ __device__ __forceinline__ void wave_select_split(const FastParams& F, SM& sm, c
   //      the last of the tail (psis.py:139: ties at the cutoff leave the tail) ------------------------------------------
   const int na = C1 - nbnd;  // candidates in the bins above: all in the tail
   const double xb = sm.sa[na + (lane < nbnd ? lane : 0)];
-  // the tail's values in the higher bins, on their way while the boundary bin is sorted out
-  double xh[HU];
-#pragma unroll
-  for (int u = 0; u < HU; ++u) {
-    const int j = lane + kWave * u;
-    xh[u] = sm.sa[j < na ? j : 0];
-  }
   int gt = 0, ge = 0;
   for (int j = 0; j < nbnd; ++j) {
     const double xj = lane_value(xb, j);
@@ -1162,38 +1171,38 @@ __device__ __forceinline__ void wave_select_split(const FastParams& F, SM& sm, c
   const double xcut = lane_value(xb, src);
   const int n = na + __builtin_amdgcn_readlane(gt, src);  // draws strictly above the cutoff
   // ---- hand-over: y = e^x - e^xcut (psis.py:147) in the candidates' order, zeros from n up to the row stride ----------
+  // The boundary bin's members above the cutoff close ranks behind the higher bins IN LDS (every lane holds its xb by now), so
+  // that the row goes out as whole 512-byte stores, nothing scattered behind them.
   const int stride = F.ws_stride;
   double* wy = F.ws_y + r * (int64_t)stride;
+  const double e_cut = exp_tab(xcut, tb.tab);
   if (n > 4) {
     const bool mine = lane < nbnd && xb > xcut;
     const unsigned long long mm = __ballot(mine);
     const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
-    // independent exponentials: the cutoff, the boundary bin's, HU of the higher bins'
-    double eh[HU];
-    const double e_cut = exp_tab(xcut, tb.tab);
-    const double eb = exp_tab(xb, tb.tab);
+    *(mine ? &sm.sa[na + (int)pos] : dump_slot) = xb;
+    wave_sync();
+    double xh[HU], eh[HU];
+#pragma unroll
+    for (int u = 0; u < HU; ++u) {
+      const int j = lane + kWave * u;
+      xh[u] = sm.sa[j < n ? j : 0];
+    }
 #pragma unroll
     for (int u = 0; u < HU; ++u) eh[u] = exp_tab(xh[u], tb.tab);
 #pragma unroll
     for (int u = 0; u < HU; ++u) {
       const int j = lane + kWave * u;
-      if (j < stride && (j < na || j >= n) && !(dbgs & 256)) wy[j] = j < na ? eh[u] - e_cut : 0.0;
+      if (kWave * u < stride && !(dbgs & 256)) ws_store<SYNC>(wy + j, j < n ? eh[u] - e_cut : 0.0);  // (wave-uniform guard)
     }
-    if (mine && !(dbgs & 256)) wy[na + (int)pos] = eb - e_cut;
-    if (lane == 0) {
-      double* ws = F.ws_s + r * 8;
-      ws[0] = m; ws[1] = mn; ws[2] = s1_all; ws[3] = s2_all; ws[4] = e_cut; ws[5] = (double)n;
-    }
-  } else if (lane == 0) {
-    double* ws = F.ws_s + r * 8;
-    ws[0] = m; ws[1] = mn; ws[2] = s1_all; ws[3] = s2_all; ws[4] = exp_tab(xcut, tb.tab); ws[5] = (double)n;
   }
+  ws_store_scalars<SYNC>(F, r, lane, m, mn, s1_all, s2_all, e_cut, (double)n);
 }
 
 // LW = false: LOO mode (input = log-likelihood, raw = -ll; outputs k-hat, loo_i, lppd_i)
 // LW = true:  weights mode (input = log ratios, raw = input; outputs k-hat and the normalised smoothed
 //             log-weights, psis.py:78-111): the row stays in its registers until the weights are stored
-template <typename T, int VEC, bool LW, typename SM, typename TB, bool SPLIT = false>
+template <typename T, int VEC, bool LW, typename SM, typename TB, bool SPLIT = false, bool SYNC = false>
 __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParams& F, SM& sm, const TB& tb, const int64_t r,
                                             T (&v)[kWaveSlots], const T* rp_next) {
   constexpr int EPT = kWaveSlots;
@@ -1213,8 +1222,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
 #else
   constexpr int dbgs = 0;
 #endif
-  const double* l1tab = tb.l1;
-  const double* bgrid = tb.bg;
   const int mestM = __builtin_amdgcn_readfirstlane(F.mest_M);
   const double logS = uniform_d(F.log_S);
   const double INF = pinf();
@@ -1425,7 +1432,8 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       why_cand = (int)ncand < M + 1 ? 1 : 2;
 #endif
     } else if constexpr (SPLIT && kFitSorts && !LW) {
-      wave_select_split(F, sm, tb, r, lane, M, m, mn, s1, s2, ncand, k1, sh, magic, c256, slow, CandInLds<SM>{sm}, dbgs);
+      wave_select_split<SM, TB, 4, CandInLds<SM>, SYNC>(F, sm, tb, r, lane, M, m, mn, s1, s2, ncand, k1, sh, magic, c256, slow,
+                                                        CandInLds<SM>{sm}, dbgs);
     } else {
       wave_back<T, VEC, LW, SM, TB, SPLIT>(P, sm, tb, r, v, lane, S, M, mestM, logS, dbgs, m, mn, R, 0.0, s1, s2, ncand, k1, sh,
                                            magic, c256, qfull, qrem, slow, khat, loo, lppd, &F);
@@ -1434,6 +1442,10 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   // the next row starts streaming into the (now dead) row registers while the outputs are stored and
   // the other wave of this SIMD computes
   PLA_PHASE(15);
+  // (tail length -1: tells the fit kernel that this observation is on the list for the general kernel)
+  if constexpr (SPLIT) {
+    if (slow) ws_store_scalars<SYNC>(F, r, lane, 0.0, 0.0, 0.0, 0.0, 0.0, -1.0);
+  }
   if constexpr (LW || PLA_WAVE_ABLATE) {
     if (!streamed && rp_next) issue_row_loads<T, VEC, LW ? 0 : PLA_LOAD_AUX>(v, rp_next, S);  // (weights mode: every row)
   }
@@ -1452,7 +1464,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
         atomicAdd(&F.counters[8 + why], 1ull);
       }
 #endif
-      if constexpr (SPLIT) F.ws_s[r * 8 + 5] = -1.0;  // tail length -1: tells the fit kernel that this observation is on the list
     } else if constexpr (!SPLIT) {
       if (P.diag) P.diag[r] = khat;
       if constexpr (!LW) {
@@ -1466,32 +1477,79 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
 // The per-row body is deliberately NOT inlined into the row loop: inlined, LLVM hoists every
 // loop-invariant constant, mask and offset of the later phases above the loop, where they sit on
 // top of the 128 row registers and spill.
-template <typename T, int VEC, bool LW, class CAP, bool SPLIT = false>
+template <typename T, int VEC, bool LW, class CAP, bool SPLIT = false, bool SYNC = false>
 __global__ __launch_bounds__(kWave * CAP::kWaves, PLA_MIN_WAVES_PER_SIMD) void wave_loo_kernel(RowsParams P, FastParams F) {
   using SM = std::conditional_t<LW, WaveSmemLWT<CAP>, WaveSmemT<CAP>>;
-  using TB = WaveTablesT<CAP>;
+  // (the selection half of the split pass needs the exponential table only: 6.5 KB of LDS less per workgroup, which is what lets
+  // a four-wave workgroup of the fit kernel sit beside two of these on a CU)
+  constexpr bool kTabOnly = SPLIT && kFitSorts && !LW;
+  using TB = std::conditional_t<kTabOnly, WaveTabOnly, WaveTablesT<CAP>>;
   constexpr int kWavesPerBlock = CAP::kWaves;
   __shared__ __attribute__((aligned(16))) SM scratch[kWavesPerBlock];
   __shared__ __attribute__((aligned(16))) TB tb;
   const int tid = threadIdx.x;
   for (int j = tid; j < kTabN; j += kWave * kWavesPerBlock) exp_table_entry(tb.tab, j);
-  for (int j = tid; j < kLogTabN; j += kWave * kWavesPerBlock) log_table_entry(tb.lt, j);
-  for (int j = tid; j < P.tail_count; j += kWave * kWavesPerBlock) tb.l1[j] = F.l1_table[j];
-  if (tid < kWave) tb.bg[tid] = F.b_grid[tid];
+  if constexpr (!kTabOnly) {
+    for (int j = tid; j < kLogTabN; j += kWave * kWavesPerBlock) log_table_entry(tb.lt, j);
+    for (int j = tid; j < P.tail_count; j += kWave * kWavesPerBlock) tb.l1[j] = F.l1_table[j];
+    if (tid < kWave) tb.bg[tid] = F.b_grid[tid];
+  }
   __syncthreads();  // the only workgroup barrier: from here on the waves are independent
   const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);  // wave-uniform, and the compiler knows it
   SM& sm = scratch[wv];
   T v[kWaveSlots];
   const T* base = reinterpret_cast<const T*>(P.in);
+  if constexpr (SYNC) {
+    if (F.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (F.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (F.prio == 3) __builtin_amdgcn_s_setprio(3);
+  }
   const int64_t w0 = (int64_t)blockIdx.x * kWavesPerBlock + wv, nw = (int64_t)gridDim.x * kWavesPerBlock;
-  if (w0 < P.n_obs) issue_row_loads<T, VEC, LW ? 0 : PLA_LOAD_AUX>(v, base + PLA_ROW_OFFSET(P, w0), P.n_draws);
 #if PLA_WAVE_ABLATE
   unsigned long long ck0, rt0;
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck0), "=s"(rt0));
 #endif
-  for (int64_t r = w0; r < P.n_obs; r += nw) {
-    const int64_t rn = r + nw;
-    wave_loo_row<T, VEC, LW, SM, TB, SPLIT>(P, F, sm, tb, r, v, rn < P.n_obs ? base + PLA_ROW_OFFSET(P, rn) : nullptr);
+  // Which rows this wave takes: with a dynamic row queue (FastParams::queue) chunks of kQueueChunk consecutive rows -- the
+  // chunk after the current one is known a chunk ahead, so that the last row of a chunk streams the first row of the next one
+  // in behind its sweep like any other row; without one, row first + i * waves.  ONE loop and one call site for both: a
+  // second copy of the row body costs the kernel fifty registers.
+  const bool queued = !LW && F.queue != nullptr;
+  const auto dequeue = [&]() -> int64_t {
+    unsigned got = 0;
+    if (wave_lane() == 0) got = atomicAdd(F.queue, (unsigned)kQueueChunk);
+    return (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)got);
+  };
+  const int64_t n = P.n_obs;
+  int64_t r = w0, nxt = 0, chunk0 = 0;
+  int left = 0;  // rows of the current chunk after row r
+  if (queued) {
+    r = dequeue();
+    nxt = dequeue();
+    left = kQueueChunk - 1;
+    chunk0 = r;
+  }
+  if (r < n) issue_row_loads<T, VEC, LW ? 0 : PLA_LOAD_AUX>(v, base + PLA_ROW_OFFSET(P, r), P.n_draws);
+#pragma unroll 1
+  while (r < n) {
+    const int64_t rn = !queued ? r + nw : (left > 0 ? r + 1 : nxt);
+    wave_loo_row<T, VEC, LW, SM, TB, SPLIT, SYNC>(P, F, sm, tb, r, v, rn < n ? base + PLA_ROW_OFFSET(P, rn) : nullptr);
+    if (queued) {
+      if (left > 0 && r + 1 < n) {
+        left -= 1;
+      } else {
+        left = kQueueChunk - 1;
+        const int64_t after = dequeue();  // (its returned value is waited for: everything this wave has stored so far has drained)
+        if constexpr (SYNC) {
+          // streamed pass: chunk chunk0 / kQueueChunk is complete -- every hand-over store of its rows (sc1, whole lines) has
+          // left this wave -- and the fit kernel beside this one may take it
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (said explicitly: the compiler may know the counter to be empty and drop its own)
+          if (wave_lane() == 0) __hip_atomic_store(F.done + chunk0 / kQueueChunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        chunk0 = nxt;
+        nxt = after;
+      }
+    }
+    r = rn;
   }
 #if PLA_WAVE_ABLATE
   if (blockIdx.x == 0 && tid == 0) {  // core clock against the 100 MHz real-time counter

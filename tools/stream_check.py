@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Streamed split pass against the two kernels back to back (PLA_PIPE=0), every observation, bit for bit, several times over
+(a stale read of the hand-over would show as a differing row).  python tools/stream_check.py [n_obs] [repeats]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pyloo_amd.base import tail_count_for  # noqa: E402
+from pyloo_amd.engine import get_engine  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 300_000
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+S = 4000
+eng = get_engine(0)
+ll = torch.empty((n, S), dtype=torch.float64, device="cuda:0")
+eng.fill_synthetic(ll, seed=0x5EED0003, k_lo=0.05, k_hi=0.9)
+ll[7, 11] = float("nan")  # a few rows for the general kernel
+ll[min(n - 1, 12345), 5] = float("inf")
+M = tail_count_for(S, 1.0)
+
+
+def run(pipe):
+    os.environ["PLA_PIPE"] = pipe
+    r = eng.psis_loo(ll, M, "psis", 1.0, 0.7)
+    torch.cuda.synchronize()
+    return [r[k].cpu().numpy().copy() for k in ("diag", "loo_i", "lppd_i")] + [r["agg"].cpu().numpy().copy()]
+
+
+ref = run("0")
+bad = 0
+for i in range(reps):
+    got = run("1")
+    for name, a, b in zip(("khat", "loo_i", "lppd_i", "agg"), ref, got):
+        same = (a == b) | (np.isnan(a) & np.isnan(b))
+        if not same.all():
+            idx = np.flatnonzero(~same)
+            bad += 1
+            print(f"rep {i}: {name} differs in {idx.size} entries, first {idx[:8]}: {a[idx[:4]]} vs {b[idx[:4]]}")
+print(f"n={n} reps={reps}: {'IDENTICAL' if not bad else 'MISMATCH'}; slow rows {ref[3][7]:.0f} / {got[3][7]:.0f}; elpd {got[3][1]:.6f}")
+sys.exit(1 if bad else 0)
