@@ -293,9 +293,10 @@ static hipError_t launch_fit_stream(const RowsParams& p, const FastParams& f, in
   q.gave_up = sync + 32;
   q.done = sync + 48;
   q.fitted = sync + 48 + nchunks;
-  // polls are ~0.3 us apart (s_sleep 32 + one load): two seconds of them, then the chunk is left to the plain fit kernel
+  // looks are 1-2 us apart (s_sleep 32 + one load from memory): a few seconds of them, then the chunk is left to the plain fit
+  // kernel that follows -- nothing then depends on the two kernels having been run side by side
   static const int patience = debug_flag("PLA_STREAM_PATIENCE");
-  q.patience = patience > 0 ? (unsigned)patience : 6000000u;
+  q.patience = patience > 0 ? (unsigned)patience : 2000000u;
   static const int fg_forced = debug_flag("PLA_FIT_GRID");
   int64_t g = nchunks < 256 ? nchunks : 256;
   if (fg_forced > 0 && fg_forced < nchunks) g = fg_forced;

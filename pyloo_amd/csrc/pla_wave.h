@@ -1190,10 +1190,12 @@ __device__ __forceinline__ void wave_select_split(const FastParams& F, SM& sm, c
     }
 #pragma unroll
     for (int u = 0; u < HU; ++u) eh[u] = exp_tab(xh[u], tb.tab);
+    int nblk = stride;  // (opaque per row: else the HU guards are evaluated above the row loop and held in scalar registers the
+    asm volatile("" : "+s"(nblk));  // long-row kernels do not have)
 #pragma unroll
     for (int u = 0; u < HU; ++u) {
       const int j = lane + kWave * u;
-      if (kWave * u < stride && !(dbgs & 256)) ws_store<SYNC>(wy + j, j < n ? eh[u] - e_cut : 0.0);  // (wave-uniform guard)
+      if (kWave * u < nblk && !(dbgs & 256)) ws_store<SYNC>(wy + j, j < n ? eh[u] - e_cut : 0.0);  // (wave-uniform guard)
     }
   }
   ws_store_scalars<SYNC>(F, r, lane, m, mn, s1_all, s2_all, e_cut, (double)n);
@@ -1514,31 +1516,33 @@ __global__ __launch_bounds__(kWave * CAP::kWaves, PLA_MIN_WAVES_PER_SIMD) void w
   // in behind its sweep like any other row; without one, row first + i * waves.  ONE loop and one call site for both: a
   // second copy of the row body costs the kernel fifty registers.
   const bool queued = !LW && F.queue != nullptr;
-  const auto dequeue = [&]() -> int64_t {
+  // (the queue's state in 32-bit scalars -- rows < 2^31 with a queue -- the row loop is short of scalar registers)
+  const auto dequeue = [&]() -> unsigned {
     unsigned got = 0;
     if (wave_lane() == 0) got = atomicAdd(F.queue, (unsigned)kQueueChunk);
-    return (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)got);
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)got);
   };
   const int64_t n = P.n_obs;
-  int64_t r = w0, nxt = 0, chunk0 = 0;
+  int64_t r = w0;
+  unsigned nxt = 0, chunk0 = 0;
   int left = 0;  // rows of the current chunk after row r
   if (queued) {
-    r = dequeue();
+    chunk0 = dequeue();
     nxt = dequeue();
     left = kQueueChunk - 1;
-    chunk0 = r;
+    r = (int64_t)chunk0;
   }
   if (r < n) issue_row_loads<T, VEC, LW ? 0 : PLA_LOAD_AUX>(v, base + PLA_ROW_OFFSET(P, r), P.n_draws);
 #pragma unroll 1
   while (r < n) {
-    const int64_t rn = !queued ? r + nw : (left > 0 ? r + 1 : nxt);
+    const int64_t rn = !queued ? r + nw : (left > 0 ? r + 1 : (int64_t)nxt);
     wave_loo_row<T, VEC, LW, SM, TB, SPLIT, SYNC>(P, F, sm, tb, r, v, rn < n ? base + PLA_ROW_OFFSET(P, rn) : nullptr);
     if (queued) {
       if (left > 0 && r + 1 < n) {
         left -= 1;
       } else {
         left = kQueueChunk - 1;
-        const int64_t after = dequeue();  // (its returned value is waited for: everything this wave has stored so far has drained)
+        const unsigned after = dequeue();  // (its returned value is waited for: everything this wave has stored so far has drained)
         if constexpr (SYNC) {
           // streamed pass: chunk chunk0 / kQueueChunk is complete -- every hand-over store of its rows (sc1, whole lines) has
           // left this wave -- and the fit kernel beside this one may take it

@@ -72,6 +72,43 @@ def test_c3_full_size(eng):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("n_obs", [5, 1000, 200_003])
+def test_streamed_pass_equals_the_kernels_back_to_back(eng, n_obs, monkeypatch):
+    """The streamed split pass (fit kernel beside the wave kernel, chunks handed over behind per-chunk flags inside one
+    launch) against the same two kernels run one after the other (PLA_PIPE=0): every output of every observation bit for bit,
+    several times over -- a stale read of the hand-over would show as a differing row.  Includes rows for the general kernel
+    and a row count that is not a multiple of the chunk."""
+    import torch
+
+    S = 4000
+    t = torch.empty((n_obs, S), dtype=torch.float64, device="cuda")
+    eng.fill_synthetic(t, seed=0x5EED0002, k_lo=0.05, k_hi=0.9)
+    t[min(7, n_obs - 1), 11] = float("inf")
+    t[n_obs // 2, 5] = -float("inf")
+    M = orc.tail_count(S, 1.0)
+
+    def run(pipe):
+        monkeypatch.setenv("PLA_PIPE", pipe)
+        r = eng.psis_loo(t, M, "psis", 1.0, 0.7)
+        torch.cuda.synchronize()
+        return {k: r[k].clone() for k in ("diag", "loo_i", "lppd_i", "agg")}
+
+    ref = run("0")
+    for _ in range(4):
+        got = run("1")
+        for k in ref:
+            same = (ref[k] == got[k]) | (torch.isnan(ref[k]) & torch.isnan(got[k]))
+            assert bool(same.all()), (k, int((~same).sum()))
+    # and against the oracle (a sample)
+    idx = np.unique(np.linspace(0, n_obs - 1, 40).astype(np.int64))
+    rows = t[torch.from_numpy(idx).to(t.device)].cpu().numpy()
+    want = orc.loo_arrays(rows, 1.0)
+    close(got["diag"].cpu().numpy()[idx], want["khat"], what="khat")
+    close(got["loo_i"].cpu().numpy()[idx], want["loo_i"], what="loo_i")
+    del t
+    torch.cuda.empty_cache()
+
+
 def test_c5_shard(eng):
     """One GPU's shard of C5: S=20 000 x N=125 000 f32 (10 GB), seed 0x5EED0005, rows with i mod 10 in {0, 3, 6} drawn
     with k in [1, 1.3): ~30 % of the observations end above khat = 0.7.  500 rows against the oracle on the upcast data."""

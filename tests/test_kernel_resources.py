@@ -19,6 +19,7 @@ KERNELS = {
     "wave_loo_kernelIfLi4ELb0ENS_9CapsSmall": 81920,   # LOO, f32
     "wave_loo_kernelIdLi2ELb1ENS_9CapsSmall": 81920,   # weights mode
     "wave_loo_kernelIdLi2ELb0ENS_9CapsSmallELb1": 81920,   # split pass: selection half
+    "wave_loo_kernelIdLi2ELb0ENS_9CapsSmallELb1ELb1": 61440,   # streamed pass: selection half, agent-scope hand-over
     "fit_rows_kernelILi3": 81920,                      # split pass: fit half (M = 190)
     "fit_rows_kernelILi4": 81920,
     "wave_loo_chunked_kernelIdLi2ENS_8CapsMid4ELb1": 81920,   # long rows / small reff, split pass (production)
@@ -36,6 +37,12 @@ KERNELS = {
     "is_wave_kernelIdLi2ELb0ELb1": 81920,              # ... weights out
     "is_wave_kernelIdLi2ELb1ELb1": 81920,
     "is_wave_kernelIfLi4ELb1ELb1": 81920,
+    # lane-per-observation kernels of the observations-fastest path, e_loo quantiles: no scratch either
+    "col_sweep_kernelId": 81920,
+    "col_sweep_kernelIf": 81920,
+    "col_select_kernel": 81920,
+    "waic_col_kernelId": 81920,
+    "e_loo_quantile_kernelIdLi256": 81920,
 }
 
 
@@ -53,3 +60,20 @@ def test_row_kernels_do_not_spill(tmp_path):
         assert not any(k.startswith("scratch_") for k in total), (name, dict(total))
         assert res.get("NumVgprs", 0) <= 256 and res.get("Occupancy", 0) >= 1, (name, res)
         assert res.get("LDSByteSize", 0) <= lds_limit, (name, res)  # two workgroups per CU (160 KB LDS)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+def test_streamed_pass_kernels_fit_on_one_cu_together(tmp_path):
+    """The streamed split pass needs two workgroups of the wave kernel AND one four-wave workgroup of the fit kernel resident on
+    every CU at once: 512 vector registers per SIMD (allocated in eights) and 160 KB of LDS are the budget."""
+    import isa_stats
+
+    lines = isa_stats.compile_isa(out=str(tmp_path / "kernels.s"))
+    _, _, _, wave = isa_stats.kernel_stats(lines, "wave_loo_kernelIdLi2ELb0ENS_9CapsSmallELb1ELb1")
+    name, total, _, fit = isa_stats.kernel_stats(lines, "fit_rows_stream_kernelILi3")
+    assert fit.get("ScratchSize", 0) == 0 and not any(k.startswith("scratch_") for k in total), (name, fit)
+    alloc = lambda v: (v + 7) // 8 * 8  # noqa: E731
+    vw, vf = wave["NumVgprs"] + wave.get("NumAgprs", 0), fit["NumVgprs"] + fit.get("NumAgprs", 0)
+    assert 2 * alloc(vw) + alloc(vf) <= 512, (vw, vf)
+    coef = 4 * 5 * 4 * 48 * 8  # dynamic LDS of the fit kernel at three 64-value blocks (fit_coef_bytes<3, 4>)
+    assert 2 * wave["LDSByteSize"] + fit["LDSByteSize"] + coef <= 160 * 1024, (wave["LDSByteSize"], fit["LDSByteSize"])
