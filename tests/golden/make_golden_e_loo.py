@@ -95,6 +95,24 @@ def main():
     # f32 inputs (the reference keeps the input dtype through exp / sort)
     x, lr = rows_case(rng, 6, 1000, np.float32)
     cases["s1000_f32"] = (x, mods["psis"].psislw(lr, 1.0)[0], lr)
+    # draws with many equal values (count / binary / rounded posterior-predictive data): the quantile is crossed INSIDE a group of
+    # equal draws in most rows, where the reference returns the value itself (e_loo.py:548-554 with x1 == x_sorted[wi]).  A
+    # generator of its own, so that the cases above keep their numbers.
+    rng2 = np.random.default_rng(20261005)
+    n, s = 10, 2000
+    x, lr = rows_case(rng2, n, s)
+    lw = mods["psis"].psislw(lr, 1.0)[0]
+    x[0] = rng2.poisson(5.0, s)
+    x[1] = rng2.poisson(0.5, s)
+    x[2] = rng2.binomial(1, 0.3, s)
+    x[3] = rng2.binomial(12, 0.4, s)
+    x[4] = np.round(x[4], 0)
+    x[5] = np.round(x[5], 1)
+    x[6] = np.floor(np.abs(x[6]) * 3.0)
+    x[7] = rng2.poisson(40.0, s)
+    x[8] = np.where(rng2.random(s) < 0.9, 0.0, x[8])  # zero-inflated
+    x[9] = np.sign(x[9])
+    cases["ties_s2000"] = (x, lw, lr)
     for name, (x, lw, lr) in cases.items():
         ref = reference_rows(mods, el, x, lw, lr)
         out[name + "_x"], out[name + "_lw"], out[name + "_lr"] = x, lw, lr

@@ -139,7 +139,7 @@ def test_vectorised_backend_equals_the_loop():
 # ---------------------------------------------------------------------------------------------
 # e_loo: weighted expectations and their k (fixtures: tests/golden/make_golden_e_loo.py, the reference's own helpers)
 # ---------------------------------------------------------------------------------------------
-E_LOO_CASES = ["s4000", "s1000", "s257", "s64", "s16", "s4", "edges_s500", "s1000_f32"]
+E_LOO_CASES = ["s4000", "s1000", "s257", "s64", "s16", "s4", "edges_s500", "s1000_f32", "ties_s2000"]
 
 
 @pytest.mark.parametrize("case", E_LOO_CASES)
