@@ -503,7 +503,6 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
   p.tail_cap = pow2_at_least(p.tail_count);
   p.scale_value = scale_value;
   p.counters = eng->counters;
-  PLA_HIP(hipMemsetAsync(eng->counters, 0, 16 * sizeof(unsigned long long), s));  // [1]: rows left to the general kernel
   if (n_obs > 0) {
     rc = grow(&eng->d_slow, &eng->d_slow_bytes, (size_t)n_obs * sizeof(unsigned));
     if (rc) return rc;
@@ -551,6 +550,8 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
     }
   }
   if (!p.ws_y) pipeline = false;
+  // [1]: rows left to the general kernel (a streamed pass zeroes the counters together with its flags: one command less)
+  if (!pipeline) PLA_HIP(hipMemsetAsync(eng->counters, 0, 16 * sizeof(unsigned long long), s));
 
   if (mem_space == PLA_DEVICE) {
     // agg needs the pointwise loo_i: use the caller's vectors, or the engine scratch
@@ -630,7 +631,7 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
       TimedLaunch t(eng, s);
       if (pipeline) {
         pla::PipeStreams ps{eng->pipe_first, eng->pipe_second, eng->pipe_fork, eng->pipe_join1, eng->pipe_join2, (unsigned*)eng->d_sync,
-                            nullptr, nullptr};
+                            nullptr, nullptr, r0 == 0};
         if (eng->timing && eng->pipe_timed < pla_engine::kPipeTimed) {
           ps.before_first = eng->pipe_t0[eng->pipe_timed];
           ps.after_first = eng->pipe_t1[eng->pipe_timed];

@@ -117,6 +117,10 @@ constexpr size_t fit_coef_bytes() { return (size_t)W * 5 * 4 * (16 * NQ) * sizeo
 template <int NQ, int G, int W, bool DYN = false, bool STREAM = false>
 __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
   static_assert(!STREAM || W * 4 == kQueueChunk, "streamed pass: one chunk of the wave kernel per workgroup and trip");
+  if constexpr (!STREAM) {
+    // behind a streamed pass, which fitted everything unless it gave up waiting: nothing to do, not even the tables
+    if (Q.fitted && Q.gave_up && *Q.gave_up == 0u) return;
+  }
   __shared__ int s_chunk;
   constexpr int kFitWaves = W;  // (shadows the default: everything below is per instantiation)
   __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];

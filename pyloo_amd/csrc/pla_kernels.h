@@ -44,6 +44,7 @@ struct PipeStreams {
   unsigned* sync;
   hipEvent_t before_first;  // optional (timing): recorded on `first` right before the first kernel ...
   hipEvent_t after_first;   // ... and right behind it
+  bool zero_all_counters;   // first launch of a call: RowsParams::counters[0..15] are zeroed with the flags (else [0] only)
 };
 size_t stream_sync_bytes(int64_t n_obs);
 

@@ -257,12 +257,14 @@ static int64_t wave_grid(int64_t n_obs, int waves) {
 }
 
 // second kernel of a split LOO pass: fit / smoothing / outputs for the tails the selection kernel handed over (pla_fit.h)
-static hipError_t launch_fit(const RowsParams& p, const FastParams& f, int mestM, hipStream_t stream, const unsigned* fitted = nullptr) {
+static hipError_t launch_fit(const RowsParams& p, const FastParams& f, int mestM, hipStream_t stream, const unsigned* fitted = nullptr,
+                             const unsigned* gave_up = nullptr) {
   FitParams q{p.ws_y, p.ws_s, p.ws_stride, p.n_obs, p.n_draws, p.tail_count, mestM, f.log_S, p.scale_value, p.l1_table,
               p.l1_table + p.tail_count, p.diag, p.loo_i, p.lppd_i, p.slow_list, p.counters};
   q.slow_base = f.slow_base;
   q.ws_sstride = f.ws_sstride;
   q.fitted = const_cast<unsigned*>(fitted);  // (behind a streamed pass: only the chunks that pass left)
+  q.gave_up = const_cast<unsigned*>(gave_up);
   static const int skip_fit = debug_flag("PLA_SKIP_FIT");  // timing experiments only: the outputs are then garbage
   if (skip_fit) return hipSuccess;
   const int nq = p.ws_stride / 64;
@@ -309,6 +311,12 @@ static hipError_t launch_fit_stream(const RowsParams& p, const FastParams& f, in
   }
   return hipGetLastError();
 }
+// zeroes two regions in one launch (the counters and the flags of a streamed pass: one command on the stream instead of two)
+__global__ __launch_bounds__(256) void zero2_kernel(unsigned* a, size_t na, unsigned* b, size_t nb) {
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = i0; i < na; i += step) a[i] = 0u;
+  for (size_t i = i0; i < nb; i += step) b[i] = 0u;
+}
 size_t stream_sync_bytes(int64_t n_obs) {
   const int64_t nchunks = (n_obs + kQueueChunk - 1) / kQueueChunk;
   return (size_t)(48 + 2 * nchunks + 16) * sizeof(unsigned);
@@ -341,8 +349,10 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, co
     *plan_stream = streamed ? 1 : 0;
     return hipSuccess;
   }
-  e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
-  if (e != hipSuccess) return e;
+  if (!streamed) {
+    e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+  }
   if constexpr (!LW) {
     if (split) {
       // split pass: wave kernel up to the exact selection, then sixteen lanes per observation for the GPD fit,
@@ -355,7 +365,13 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, co
         // streamed: the fit kernel runs beside the wave kernel and takes the chunks as they are finished
         unsigned* const sync = pipe->sync;
         const int64_t nchunks = (p.n_obs + kQueueChunk - 1) / kQueueChunk;
-        e = hipMemsetAsync(sync, 0, stream_sync_bytes(p.n_obs), stream);
+        {
+          const size_t nsync = stream_sync_bytes(p.n_obs) / sizeof(unsigned);
+          const unsigned zg = (unsigned)((nsync + 1023) / 1024 < 256 ? (nsync + 1023) / 1024 : 256);
+          hipLaunchKernelGGL(zero2_kernel, dim3(zg ? zg : 1), dim3(256), 0, stream, reinterpret_cast<unsigned*>(p.counters),
+                             (size_t)(pipe->zero_all_counters ? 32 : 2), sync, nsync);
+          e = hipGetLastError();
+        }
         if (e == hipSuccess) e = hipEventRecord(pipe->fork, stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(pipe->first, pipe->fork, 0);
         if (e == hipSuccess) e = hipStreamWaitEvent(pipe->second, pipe->fork, 0);
@@ -381,7 +397,7 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, co
         if (e == hipSuccess) e = hipStreamWaitEvent(stream, pipe->join_second, 0);
         if (e != hipSuccess) return e;
         // whatever the streamed fit left (nothing, unless it gave up waiting for the wave kernel)
-        e = launch_fit(p, f, mestM, stream, sync + 48 + nchunks);
+        e = launch_fit(p, f, mestM, stream, sync + 48 + nchunks, sync + 32);
         if (e != hipSuccess) return e;
       } else {
         static const int queue_too = debug_flag("PLA_QUEUE");  // A/B: dynamic row queue without the streamed fit

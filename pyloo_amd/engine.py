@@ -173,7 +173,7 @@ class Engine:
         diag = torch.empty(m, dtype=torch.float64, device=dev) if (pointwise or aggregate) else None
         loo_i = torch.empty(m, dtype=torch.float64, device=dev) if (pointwise or aggregate) else None
         lppd_i = torch.empty(m, dtype=torch.float64, device=dev) if (pointwise or aggregate) else None
-        agg = torch.zeros(AGG_COUNT, dtype=torch.float64, device=dev) if aggregate else None
+        agg = torch.empty(AGG_COUNT, dtype=torch.float64, device=dev) if aggregate else None  # (every slot is written)
         p = lambda x: None if x is None else C.c_void_p(x.data_ptr())  # noqa: E731
         code = _capi.PLA_F64 if t.dtype == torch.float64 else _capi.PLA_F32
         if idx is not None:
