@@ -48,8 +48,8 @@ constexpr int kFitCoefStride = 6;  // (VALU grid pass) doubles per quad in LDS, 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 struct FitParams {
-  const double* ws_y;   // [n_obs][ws_stride] ascending tail values, zero padded; ws_stride = 64 NQ
-  const double* ws_s;   // [n_obs][8]: max raw, min raw, sum_all e^x, sum_all e^-x, e^xcut, n (-1: declined), -, -
+  const double* ws_y;   // [n_obs][ws_stride] the tail's shifted log ratios x, grouped by selection bin (bins descending), padded with the cutoff; ws_stride = 64 NQ
+  const double* ws_s;   // [n_obs][ws_sstride]: max raw, min raw, sum_all e^x, sum_all e^-x, xcut, n (-1: declined), -, -
   int ws_stride;
   int64_t n_obs;
   int n_draws;
@@ -121,7 +121,7 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     // behind a streamed pass, which fitted everything unless it gave up waiting: nothing to do, not even the tables
     if (Q.fitted && Q.gave_up && *Q.gave_up == 0u) return;
   }
-  __shared__ int s_chunk;
+  __shared__ int s_chunk[2];
   constexpr int kFitWaves = W;  // (shadows the default: everything below is per instantiation)
   __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];
   __shared__ __attribute__((aligned(16))) double lt[2 * kLogTabN];
@@ -191,43 +191,8 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
   const int64_t ngroups = (Q.n_obs + 3) >> 2;
   const int t_lane = t;
   const int64_t nchunks = (Q.n_obs + kQueueChunk - 1) / kQueueChunk;
-  int64_t grp = (int64_t)blockIdx.x * kFitWaves + wv;
-  int prev_chunk = -1;
-  for (;; grp += (int64_t)gridDim.x * kFitWaves) {
-    if constexpr (STREAM) {
-      // the next chunk in order, once the wave kernel has finished it: one lane takes it and polls (agent-scope loads, a
-      // sleep in between); the workgroup barrier stands between that poll and every load of the chunk's bytes
-      __syncthreads();  // (everybody is done with s_chunk, and with the chunk, of the previous trip)
-      if (tid == 0) {
-        if (prev_chunk >= 0) Q.fitted[prev_chunk] = 1u;
-        int c = (int)atomicAdd(Q.take, 1u);
-        if ((int64_t)c < nchunks) {
-          unsigned looks = 0;
-          while (__hip_atomic_load(Q.done + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            if (++looks > Q.patience) {
-              __hip_atomic_store(Q.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              c = -1;
-              break;
-            }
-            __builtin_amdgcn_s_sleep(PLA_STREAM_SLEEP);
-          }
-        } else {
-          c = -1;
-        }
-        s_chunk = c;
-      }
-      __syncthreads();
-      const int c = s_chunk;
-      prev_chunk = c;
-      if (c < 0) break;
-      grp = (int64_t)c * (kQueueChunk / 4) + wv;
-      if (grp >= ngroups) continue;  // (the last chunk may be short)
-    } else {
-      if (grp >= ngroups) break;
-      if (Q.fitted) {  // behind a streamed pass: only what that pass left (nothing, unless it gave up waiting)
-        if (Q.fitted[grp / (kQueueChunk / 4)] != 0u) continue;
-      }
-    }
+  // one group of four observations, one per 16-lane row of this wave
+  const auto fit_group = [&](const int64_t grp) __attribute__((always_inline)) {
     // (opaque per group: the ranks, table offsets and LDS addresses derived from the lane number are then computed where they
     // are used instead of being hoisted above the loop, where a dozen of them sit on the register budget of the slim variant)
     int t = t_lane;
@@ -237,11 +202,12 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     const int64_t r = inrange ? r0 : Q.n_obs - 1;
     const int64_t sc = r * Q.ws_sstride;
     const double2 sc01 = ws_load2<STREAM>(Q.ws_s, sc), sc23 = ws_load2<STREAM>(Q.ws_s, sc + 2), sc45 = ws_load2<STREAM>(Q.ws_s, sc + 4);
-    const double m = sc01.x, mn = sc01.y, s1 = sc23.x, s2 = sc23.y, e_cut = sc45.x;
+    const double m = sc01.x, mn = sc01.y, s1 = sc23.x, s2 = sc23.y, xcut = sc45.x;
     const int nraw = (int)sc45.y;
     const bool handled = inrange && nraw >= 0;  // (else: past the end, or declined by the wave kernel and already listed)
     const int n = nraw < 0 ? 0 : (nraw > M ? M : nraw);
-    const bool fit = n > 4;  // psis.py:139: shorter tails are neither fitted nor smoothed (their y was not written)
+    const bool fit = n > 4;  // psis.py:139: shorter tails are neither fitted nor smoothed (their x was not written)
+    const double e_cut = exp_tab(xcut, tab);  // (hand-over: shifted log ratios; the exponentials are taken here)
     const int64_t y0 = r * (int64_t)Q.ws_stride;
     const double* y = Q.ws_y + y0;
     double2 yv[2 * NQ];  // element j = 32 i + 2 t + {0, 1}
@@ -291,6 +257,9 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
       for (int it = 0; it < 4; ++it) sort_round();
 #pragma unroll 1
       for (int it = 0; it < 8 * K && unsorted(); ++it) sort_round();
+      // y = e^x - e^xcut (psis.py:147) of the sorted tail; ranks from n on are padding (x = xcut): y = 0 exactly
+#pragma unroll
+      for (int i = 0; i < 2 * NQ; ++i) yv[i] = make_double2(exp_tab(yv[i].x, tab) - e_cut, exp_tab(yv[i].y, tab) - e_cut);
 #pragma unroll
       for (int i = 0; i < 2 * NQ; ++i) *reinterpret_cast<double2*>(ys + K * t + 2 * i) = yv[i];
       wave_sync();
@@ -540,6 +509,65 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
         if (Q.loo_i) Q.loo_i[r] = Q.scale_value * loo;
         if (Q.lppd_i) Q.lppd_i[r] = lppd;
       }
+    }
+  };
+  if constexpr (STREAM) {
+    // The chunks in order, each once the wave kernel has finished it.  One lane takes the next chunk number (a returning atomic:
+    // issued before this chunk's arithmetic, used behind it), looks at its flag (agent-scope loads, a sleep in between) and
+    // posts it in LDS; the workgroup barrier stands between that poll and every load of the chunk's bytes.
+    if (tid == 0) {
+      int c = (int)atomicAdd(Q.take, 1u);
+      if ((int64_t)c < nchunks) {
+        unsigned looks = 0;
+        while (__hip_atomic_load(Q.done + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          if (++looks > Q.patience) {
+            __hip_atomic_store(Q.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c = -1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(PLA_STREAM_SLEEP);
+        }
+      } else {
+        c = -1;
+      }
+      s_chunk[0] = c;
+    }
+    int prev_chunk = -1;
+    for (int trip = 0;; ++trip) {
+      __syncthreads();  // (s_chunk[trip & 1] is posted; everybody is done with the chunk of the previous trip)
+      const int c = s_chunk[trip & 1];
+      int nxt = -1;
+      if (tid == 0) {
+        if (prev_chunk >= 0) Q.fitted[prev_chunk] = 1u;
+        if (c >= 0) nxt = (int)atomicAdd(Q.take, 1u);
+      }
+      prev_chunk = c;
+      if (c < 0) break;
+      const int64_t grp = (int64_t)c * (kQueueChunk / 4) + wv;
+      if (grp < ngroups) fit_group(grp);  // (the last chunk may be short)
+      if (tid == 0) {
+        if ((int64_t)nxt < nchunks) {
+          unsigned looks = 0;
+          while (__hip_atomic_load(Q.done + nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            if (++looks > Q.patience) {
+              __hip_atomic_store(Q.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              nxt = -1;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(PLA_STREAM_SLEEP);
+          }
+        } else {
+          nxt = -1;
+        }
+        s_chunk[(trip + 1) & 1] = nxt;
+      }
+    }
+  } else {
+    for (int64_t grp = (int64_t)blockIdx.x * kFitWaves + wv; grp < ngroups; grp += (int64_t)gridDim.x * kFitWaves) {
+      if (Q.fitted) {  // behind a streamed pass: only what that pass left (nothing, unless it gave up waiting)
+        if (Q.fitted[grp / (kQueueChunk / 4)] != 0u) continue;
+      }
+      fit_group(grp);
     }
   }
 }

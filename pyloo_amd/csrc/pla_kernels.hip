@@ -285,7 +285,8 @@ static hipError_t launch_fit(const RowsParams& p, const FastParams& f, int mestM
 }
 // Streamed pass, the fit kernel that runs beside the wave kernel: ONE four-wave workgroup per CU is what fits there (128
 // registers per lane, 39.5 KB of LDS next to two workgroups of the wave kernel), and the workgroups stay for the whole launch
-static hipError_t launch_fit_stream(const RowsParams& p, const FastParams& f, int mestM, unsigned* sync, hipStream_t stream) {
+static hipError_t launch_fit_stream(const RowsParams& p, const FastParams& f, int mestM, unsigned* sync, hipStream_t stream,
+                                    bool helper = false) {
   FitParams q{p.ws_y, p.ws_s, p.ws_stride, p.n_obs, p.n_draws, p.tail_count, mestM, f.log_S, p.scale_value, p.l1_table,
               p.l1_table + p.tail_count, p.diag, p.loo_i, p.lppd_i, p.slow_list, p.counters};
   q.slow_base = f.slow_base;
@@ -302,6 +303,15 @@ static hipError_t launch_fit_stream(const RowsParams& p, const FastParams& f, in
   static const int fg_forced = debug_flag("PLA_FIT_GRID");
   int64_t g = nchunks < 256 ? nchunks : 256;
   if (fg_forced > 0 && fg_forced < nchunks) g = fg_forced;
+  if (helper) {
+    // a second launch of the same kernel BEHIND the wave kernel on its stream: the fit kernel beside the wave kernel lives on
+    // what that kernel leaves it and ends a few per cent of the chunks behind; once the wave kernel is gone these workgroups
+    // (three more per CU) take chunks from the same counter and the tail is over in a few trips
+    static const int hg = debug_flag("PLA_FIT_HELPERS");
+    g = hg > 0 ? hg : (hg < 0 ? 0 : 768);
+    if (g > nchunks) g = nchunks;
+    if (g < 1) return hipSuccess;
+  }
   const dim3 sg((unsigned)g), sb(kWave * 4);
   switch (p.ws_stride / 64) {  // (the coefficient scratch is dynamic LDS: pla_fit.h, DYN)
     case 1: hipLaunchKernelGGL(fit_rows_stream_kernel<1>, sg, sb, (fit_coef_bytes<1, 4>()), stream, q); break;
@@ -391,6 +401,7 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, co
         if (e != hipSuccess) return e;
         if (pipe->after_first) (void)hipEventRecord(pipe->after_first, pipe->first);
         e = launch_fit_stream(p, f, mestM, sync, pipe->second);
+        if (e == hipSuccess) e = launch_fit_stream(p, f, mestM, sync, pipe->first, true);
         if (e == hipSuccess) e = hipEventRecord(pipe->join_first, pipe->first);
         if (e == hipSuccess) e = hipEventRecord(pipe->join_second, pipe->second);
         if (e == hipSuccess) e = hipStreamWaitEvent(stream, pipe->join_first, 0);

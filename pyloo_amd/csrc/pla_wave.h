@@ -55,6 +55,7 @@ constexpr double kCancelGuard = PLA_CANCEL_GUARD;
 #define PLA_FIT_SORTS 1
 #endif
 constexpr bool kFitSorts = PLA_FIT_SORTS != 0;
+static_assert(PLA_FIT_SORTS == 1, "the hand-over is the tail's x grouped by bin (wave_select_split): the fit kernel sorts and exponentiates");
 
 #ifndef PLA_WAVE_SLOTS
 #define PLA_WAVE_SLOTS 64
@@ -1170,35 +1171,33 @@ __device__ __forceinline__ void wave_select_split(const FastParams& F, SM& sm, c
   const int src = __ffsll((long long)isc) - 1;
   const double xcut = lane_value(xb, src);
   const int n = na + __builtin_amdgcn_readlane(gt, src);  // draws strictly above the cutoff
-  // ---- hand-over: y = e^x - e^xcut (psis.py:147) in the candidates' order, zeros from n up to the row stride ----------
+  // ---- hand-over: the tail's shifted log ratios x (psis.py:139) in the candidates' order, the cutoff itself from n up to the row
+  // stride (it sorts behind every tail value and its y is exactly 0), and the cutoff; the exponentials y = e^x - e^xcut (psis.py:147) are the fit kernel's, which has lanes to spare for them ----
   // The boundary bin's members above the cutoff close ranks behind the higher bins IN LDS (every lane holds its xb by now), so
   // that the row goes out as whole 512-byte stores, nothing scattered behind them.
   const int stride = F.ws_stride;
   double* wy = F.ws_y + r * (int64_t)stride;
-  const double e_cut = exp_tab(xcut, tb.tab);
   if (n > 4) {
     const bool mine = lane < nbnd && xb > xcut;
     const unsigned long long mm = __ballot(mine);
     const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
     *(mine ? &sm.sa[na + (int)pos] : dump_slot) = xb;
     wave_sync();
-    double xh[HU], eh[HU];
+    double xh[HU];
 #pragma unroll
     for (int u = 0; u < HU; ++u) {
       const int j = lane + kWave * u;
       xh[u] = sm.sa[j < n ? j : 0];
     }
-#pragma unroll
-    for (int u = 0; u < HU; ++u) eh[u] = exp_tab(xh[u], tb.tab);
     int nblk = stride;  // (opaque per row: else the HU guards are evaluated above the row loop and held in scalar registers the
     asm volatile("" : "+s"(nblk));  // long-row kernels do not have)
 #pragma unroll
     for (int u = 0; u < HU; ++u) {
       const int j = lane + kWave * u;
-      if (kWave * u < nblk && !(dbgs & 256)) ws_store<SYNC>(wy + j, j < n ? eh[u] - e_cut : 0.0);  // (wave-uniform guard)
+      if (kWave * u < nblk && !(dbgs & 256)) ws_store<SYNC>(wy + j, j < n ? xh[u] : xcut);  // (wave-uniform guard)
     }
   }
-  ws_store_scalars<SYNC>(F, r, lane, m, mn, s1_all, s2_all, e_cut, (double)n);
+  ws_store_scalars<SYNC>(F, r, lane, m, mn, s1_all, s2_all, xcut, (double)n);
 }
 
 // LW = false: LOO mode (input = log-likelihood, raw = -ll; outputs k-hat, loo_i, lppd_i)
