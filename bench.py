@@ -45,6 +45,20 @@ def measured_traffic(n_obs, n_draws, dtype):
     return None, None
 
 
+def host_cpu_model():
+    """Model string of the host CPU (BASELINE.md section 4 asks for it beside the core count)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+
+    return platform.processor() or platform.machine()
+
+
 def launch_ranks(n):
     """Start ``n`` ranks of this script through torch.distributed.run (children of a parent that never initialises
     the GPU), pass their output through and return the launcher's exit code."""
@@ -57,7 +71,22 @@ def launch_ranks(n):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    # fresh children only (this parent has not touched the GPU and never re-executes itself); a launch that hangs -- a rank
+    # that never reaches the rendezvous -- ends with a non-zero exit code instead of holding the node
+    limit = float(os.environ.get("PYLOO_AMD_BENCH_LAUNCH_TIMEOUT", "1500"))
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        import signal
+
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)  # (the launcher's own process group: exactly what this call started)
+        except ProcessLookupError:
+            pass
+        proc.wait()
+        print(f"bench.py: the {n}-rank launch did not finish within {limit:.0f} s", file=sys.stderr)
+        return 124
 
 
 def main():
@@ -85,6 +114,9 @@ def main():
     elif args.config == "C5":  # 70 % rows k ~ U(0.05, 0.5), 30 % rows k ~ U(1.0, 1.3)
         args.obs, args.draws, args.dtype, args.seed = 125_000, 20000, "f32", 0x5EED0005
         heavy, k_hi = (1.0, 1.3), 0.5
+    if args.config is None and args.gpus == 8 and (args.draws, args.dtype, args.obs, args.seed) == (4000, "f64", 1_000_000, 0x5EED0003):
+        # the default workload on a whole node IS BASELINE.json's C4 (8 M x 4000 f64, observation-sharded): its seed and label
+        args.config, args.seed = "C4", 0x5EED0004
     label = args.config or ("C3" if (args.draws, args.dtype, args.obs) == (4000, "f64", 1_000_000) else "custom")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -116,7 +148,7 @@ def main():
 
     from pyloo_amd.base import tail_count_for
     from pyloo_amd.engine import get_engine
-    from pyloo_amd.sharded import all_reduce_aggregates
+    from pyloo_amd.sharded import all_reduce_aggregates, all_reduce_aggregates_device
 
     eng = get_engine(dev_index)
     S, n_local = args.draws, args.obs
@@ -133,7 +165,11 @@ def main():
     def step():
         res = eng.psis_loo(ll, M, "psis", 1.0, good_k, pointwise=False, aggregate=True)
         if world > 1:
-            return all_reduce_aggregates(res["agg"], as_tensor=True)  # the single collective; merged on the device, no host sync
+            # the single collective.  RCCL: pack kernel + all-reduce of the preallocated world x 8 table + merge kernel, all on
+            # the device, nothing allocated, no host sync (gloo rehearsals: the same table through host memory)
+            if backend == "nccl":
+                return all_reduce_aggregates_device(res["agg"], eng)
+            return all_reduce_aggregates(res["agg"], as_tensor=True)
         return res["agg"]
 
     def fence():
@@ -164,9 +200,15 @@ def main():
 
     # ---- roofline of the LOO pass: wave kernel (selection) + fit kernel + the rows handed to the general kernel,
     #      timed together with HIP events on the launch stream
-    kernel_ms = k_ms / max(k_n, 1)
+    kernel_ms = k_ms / max(args.steps, 1)  # per PASS (a pass over more than 2^20 rows is several bracketed launches)
     alg_bytes = n_local * (S * esz + 24.0)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    kernels_text = eng.last_kernels()
+    per_rank = None
+    if world > 1:
+        mine = {"rank": rank, "device": dev_index, "name": torch.cuda.get_device_name(dev_index), "kernel_ms": kernel_ms}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank != 0:
         if world > 1:
@@ -182,6 +224,9 @@ def main():
         "n_gpus": world,
         "ranks": world,
         "backend": (backend if world > 1 else None),
+        "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 and backend == "nccl" else None),
+        "devices_seen": ([r["device"] for r in per_rank] if per_rank else [dev_index]),
+        "kernel_ms_per_rank": ({"min": min(r["kernel_ms"] for r in per_rank), "max": max(r["kernel_ms"] for r in per_rank)} if per_rank else None),
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
@@ -210,8 +255,7 @@ def main():
                                "this run)") if traffic_file else None,
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes,
-            "kernels": "whole pass: wave_loo_kernel (statistics, sweep, tail selection) + fit_rows_kernel (GPD fit, smoothing, "
-                       "outputs) + slow_rows_kernel (declined rows), one event pair around all three",
+            "kernels": "whole pass, one event pair on the caller's stream around: " + kernels_text,
         },
     }
 
@@ -219,7 +263,7 @@ def main():
         # the dominant kernel alone (it reads the whole matrix; the fit kernel only sees the <= 250 tail values per observation)
         first_ms = f_ms / f_n
         out["roofline"]["dominant_kernel"] = {
-            "name": "wave_loo_kernel" if S <= 4096 and M <= 250 else "wave_loo_chunked_kernel", "kernel_ms": first_ms, "achieved": alg_bytes / (first_ms * 1e-3) / 1e9,
+            "name": kernels_text.split("<")[0].split(" ")[0], "kernel_ms": first_ms, "achieved": alg_bytes / (first_ms * 1e-3) / 1e9,
             "frac": alg_bytes / (first_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         }
 
@@ -248,6 +292,8 @@ def main():
             "value": done / t_cpu if t_cpu > 0 else None,
             "unit": "obs/s",
             "cores": 1,
+            "host_cpu": host_cpu_model(),
+            "host_cores": os.cpu_count(),
             "kind": "port",
             "sample": f"first {done} observations of rank 0's matrix, NumPy oracle (per-observation loop "
                       f"restating pyloo utils.py:171-175 + psis.py:114-160 + loo.py:289-337), {t_cpu:.1f} s",

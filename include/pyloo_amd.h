@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define PLA_ABI_VERSION 2
+#define PLA_ABI_VERSION 3
 
 /* status codes */
 #define PLA_OK 0
@@ -226,6 +226,23 @@ int pla_engine_kernel_ms(pla_engine *eng, double *total_ms, int64_t *launches);
 /* Same, for the first (dominant) kernel alone of the passes that ran as two kernels (the split PSIS-LOO pass: the
  * wave kernel up to the tail selection); device-pointer calls only.  Read it before or after pla_engine_kernel_ms. */
 int pla_engine_first_kernel_ms(pla_engine *eng, double *total_ms, int64_t *launches);
+
+/* Which kernels the engine's last PSIS-LOO / weights call launched, as text ("wave_loo_kernel<double> (streamed) +
+ * fit_rows_stream_kernel beside it + ..."): for benchmark records, so that what a roofline line names is what ran.
+ * Copies at most cap - 1 characters and a terminating 0 into buf. */
+int pla_engine_last_kernels(pla_engine *eng, char *buf, int cap);
+
+/*
+ * Observation-sharded runs (loo.py:326-342 across devices): every device reduces its own block of
+ * observations to one aggregate vector; the vectors are exchanged with ONE all-reduce (sum) of a world x PLA_AGG_COUNT
+ * table in which every rank has filled its own row -- the host's collective library does that (torch.distributed / RCCL
+ * in pyloo_amd.sharded; any all-reduce of doubles will do) -- and merged with the pairwise update of Chan, Golub & LeVeque.
+ * Device pointers, the caller's stream, one small kernel each:
+ *   pla_aggregate_pack   table[world][PLA_AGG_COUNT] = 0 except row `rank` = agg   (before the all-reduce)
+ *   pla_aggregate_merge  out[PLA_AGG_COUNT] = the merged aggregates of the table   (after it; identical on every rank)
+ */
+int pla_aggregate_pack(pla_engine *eng, const double *agg, int rank, int world, double *table, void *stream);
+int pla_aggregate_merge(pla_engine *eng, const double *table, int world, double *out, void *stream);
 
 /* Synthetic benchmark input, generated on the device:
  *   u = splitmix64(seed ^ (i*S + s)) -> 53-bit uniform in (0,1) -> E = -log1p(-u)

@@ -12,7 +12,7 @@ PLA_PSIS, PLA_SIS, PLA_TIS = 0, 1, 2
 METHOD_CODES = {"psis": PLA_PSIS, "sis": PLA_SIS, "tis": PLA_TIS}
 AGG_N, AGG_SUM_LOO, AGG_M2_LOO, AGG_SUM_LPPD, AGG_N_HIGH, AGG_N_NONFINITE, AGG_MIN_DIAG, AGG_N_SLOW = range(8)
 AGG_COUNT = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol declared in include/pyloo_amd.h
 SYMBOLS = (
@@ -20,6 +20,7 @@ SYMBOLS = (
     "pla_tail_count", "pla_psis_loo", "pla_importance_weights", "pla_reduce_pointwise", "pla_waic",
     "pla_psis_loo_rows", "pla_waic_rows", "pla_e_loo", "pla_e_loo_quantiles",
     "pla_engine_set_frozen", "pla_engine_set_timing", "pla_engine_kernel_ms", "pla_engine_first_kernel_ms", "pla_fill_synthetic",
+    "pla_engine_last_kernels", "pla_aggregate_pack", "pla_aggregate_merge",
 )
 
 
@@ -76,6 +77,9 @@ def load_library():
     lib.pla_engine_kernel_ms.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
     lib.pla_engine_first_kernel_ms.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
     lib.pla_fill_synthetic.argtypes = [vp, vp, ci, i64, i64, i64, C.c_uint64, dbl, dbl, dbl, dbl, vp]
+    lib.pla_engine_last_kernels.argtypes = [vp, C.c_char_p, ci]
+    lib.pla_aggregate_pack.argtypes = [vp, vp, ci, ci, vp, vp]
+    lib.pla_aggregate_merge.argtypes = [vp, vp, ci, vp, vp]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError if the header and the library disagree
         if name != "pla_last_error":

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/pyloo_amd.h"
@@ -94,6 +95,7 @@ struct pla_engine {
   static constexpr int kPipeTimed = 64;
   hipEvent_t pipe_t0[kPipeTimed] = {}, pipe_t1[kPipeTimed] = {};
   int pipe_timed = 0;
+  std::string last_kernels;  // pla_engine_last_kernels
 };
 
 namespace {
@@ -363,6 +365,31 @@ int pla_engine_first_kernel_ms(pla_engine* e, double* total_ms, int64_t* launche
   return PLA_OK;
 }
 
+int pla_engine_last_kernels(pla_engine* eng, char* buf, int cap) {
+  if (!eng || !buf || cap < 1) return fail(PLA_ERR_ARG, "engine / buffer is NULL");
+  EngineCall call(eng);
+  snprintf(buf, (size_t)cap, "%s", eng->last_kernels.c_str());
+  return PLA_OK;
+}
+
+int pla_aggregate_pack(pla_engine* eng, const double* agg, int rank, int world, double* table, void* stream) {
+  if (!eng || !agg || !table) return fail(PLA_ERR_ARG, "engine / agg / table is NULL");
+  if (world < 1 || rank < 0 || rank >= world) return fail(PLA_ERR_ARG, "need 0 <= rank < world");
+  EngineCall call(eng);
+  PLA_HIP(hipSetDevice(eng->device));
+  PLA_HIP(pla::launch_aggregate_pack(agg, rank, world, table, (hipStream_t)stream));
+  return PLA_OK;
+}
+
+int pla_aggregate_merge(pla_engine* eng, const double* table, int world, double* out, void* stream) {
+  if (!eng || !table || !out) return fail(PLA_ERR_ARG, "engine / table / out is NULL");
+  if (world < 1) return fail(PLA_ERR_ARG, "world < 1");
+  EngineCall call(eng);
+  PLA_HIP(hipSetDevice(eng->device));
+  PLA_HIP(pla::launch_aggregate_merge(table, world, out, (hipStream_t)stream));
+  return PLA_OK;
+}
+
 int pla_reduce_pointwise(pla_engine* eng, const double* diag, const double* loo_i, const double* lppd_i,
                          int64_t n_obs, double good_k, int mem_space, void* stream, double* agg) {
   if (!eng) return fail(PLA_ERR_ARG, "engine is NULL");
@@ -580,6 +607,7 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
         p.loo_i = dl ? dl + r0 : nullptr;
         p.lppd_i = dp ? dp + r0 : nullptr;
         PLA_HIP(pla::launch_col(p, dtype, col_kq, eng->d_col, s));
+        eng->last_kernels = "col_sweep_kernel (one lane per observation, matrix read in place) + col_select_kernel + fit_rows_kernel + slow_rows_kernel";
       }
       if (agg) {
         pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, agg, eng->counters + 1};
@@ -605,6 +633,7 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
         p.loo_i = dl ? dl + r0 : nullptr;
         p.lppd_i = dp ? dp + r0 : nullptr;
         PLA_HIP(pla::launch_rows(p, dtype, false, s));
+      eng->last_kernels = pla::last_rows_kernels();
       }
       if (agg) {
         pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, agg, eng->counters + 1};
@@ -638,8 +667,10 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
           eng->pipe_timed += 1;
         }
         PLA_HIP(pla::launch_rows(p, dtype, false, s, nullptr, nullptr, &ps));
+      eng->last_kernels = pla::last_rows_kernels();
       } else {
         PLA_HIP(pla::launch_rows(p, dtype, false, s, t.mid(), t.mid_flag()));
+      eng->last_kernels = pla::last_rows_kernels();
       }
     }
 #if defined(PLA_WAVE_ABLATE) && PLA_WAVE_ABLATE
@@ -704,6 +735,7 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
     {
       TimedLaunch t(eng, s);
       PLA_HIP(pla::launch_rows(p, dtype, false, s));
+      eng->last_kernels = pla::last_rows_kernels();
     }
     PLA_HIP(hipStreamSynchronize(s));  // the staging buffer is reused by the next chunk
   }
@@ -785,6 +817,7 @@ int pla_importance_weights(pla_engine* eng, const void* logw, int dtype, int64_t
         p.diag = diag ? diag + r0 : nullptr;
         p.lw_out = (char*)lw_out + (size_t)r0 * (size_t)n_draws * esz;
         PLA_HIP(pla::launch_rows(p, dtype, true, s));
+      eng->last_kernels = pla::last_rows_kernels();
       }
       return PLA_OK;
     }
@@ -795,6 +828,7 @@ int pla_importance_weights(pla_engine* eng, const void* logw, int dtype, int64_t
     p.lw_out = lw_out;
     TimedLaunch t(eng, s);
     PLA_HIP(pla::launch_rows(p, dtype, true, s));
+      eng->last_kernels = pla::last_rows_kernels();
     return PLA_OK;
   }
 
@@ -828,6 +862,7 @@ int pla_importance_weights(pla_engine* eng, const void* logw, int dtype, int64_t
     {
       TimedLaunch t(eng, s);
       PLA_HIP(pla::launch_rows(p, dtype, true, s));
+      eng->last_kernels = pla::last_rows_kernels();
     }
     PLA_HIP(hipMemcpyAsync((char*)lw_out + (size_t)r0 * row_bytes, eng->d_lw, (size_t)nr * row_bytes,
                            hipMemcpyDeviceToHost, s));

@@ -73,6 +73,11 @@ hipError_t launch_reduce(const ReduceParams& p, double* workspace, hipStream_t s
 // out[i] = min(max(in[i], 0), n_src - 1): a caller's device index list can never make a row kernel read outside the matrix
 hipError_t launch_clamp_rows(const int64_t* in, int64_t n_rows, int64_t n_src, int64_t* out, hipStream_t stream);
 int reduce_workspace_doubles();  // size of `workspace` (device memory)
+// observation-sharded runs: a rank's row of the world x 8 table (the other rows zero) / the Chan merge of the summed table
+hipError_t launch_aggregate_pack(const double* agg, int rank, int world, double* table, hipStream_t stream);
+hipError_t launch_aggregate_merge(const double* table, int world, double* out, hipStream_t stream);
+// text for pla_engine_last_kernels: what the last launch_rows() on this thread launched
+const char* last_rows_kernels();
 // Observations-fastest ingestion: ArviZ keeps log-likelihoods as (chain, draw, *obs), so the
 // (obs, sample) view pyloo stacks (loo.py:189) has unit stride along the observations.  Rows [obs0, obs0 + n_rows) of
 // such a matrix (element (i, s) at in[s * stride_draw + i]) are written as a contiguous (n_rows, n_draws) block.

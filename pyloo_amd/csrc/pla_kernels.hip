@@ -13,6 +13,7 @@
 // lw_s + ll_s == -max - LSE exactly in real arithmetic, so only the <= M tail terms need an exp.
 #include <cmath>
 #include <cstdio>
+#include <cstdarg>
 #include <cstdlib>
 
 #include "pla_fast.h"
@@ -177,6 +178,17 @@ __global__ __launch_bounds__(256) void fill_kernel(T* ll, int64_t n_obs, int64_t
 // ------------------------------------------------------------------------------------------
 int max_tail_count() { return 8192; }
 
+// what the last launch_rows() of this thread launched (pla_engine_last_kernels: benchmark records name what ran)
+static thread_local char g_last_kernels[320] = "";
+static void note_kernels(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_kernels, sizeof(g_last_kernels), fmt, ap);
+  va_end(ap);
+}
+const char* last_rows_kernels() { return g_last_kernels; }
+template <typename T> static const char* tname() { return sizeof(T) == 8 ? "double" : "float"; }
+
 template <typename T, int BLOCK, int EPT, bool LW>
 static hipError_t launch_one(const RowsParams& p, hipStream_t stream) {
   const size_t lds = smem_bytes(BLOCK, p.tail_cap);
@@ -189,6 +201,7 @@ static hipError_t launch_one(const RowsParams& p, hipStream_t stream) {
   int64_t grid = p.n_obs;
   const int64_t cap = 256 * 64;  // >> 256 CUs; rows are strided over the grid
   if (grid > cap) grid = cap;
+  note_kernels("rows_kernel<%s, %d> (general kernel: one workgroup per observation)", tname<T>(), BLOCK);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds, stream, p);
   return hipGetLastError();
 }
@@ -394,6 +407,9 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, co
         f.prio = wprio ? atoi(wprio) : 3;
         const int64_t need = (p.n_obs + kWavesPerBlock * kQueueChunk - 1) / (kWavesPerBlock * kQueueChunk);
         const int64_t g1 = need < 512 ? need : 512;  // two resident workgroups per CU take everything there is from the queue
+        note_kernels("wave_loo_kernel<%s, SPLIT, SYNC> (statistics, sweep, tail selection; dynamic row queue) with "
+                     "fit_rows_stream_kernel<%d> beside it on a second stream (GPD fit, smoothing, outputs; chunks taken behind "
+                     "per-chunk flags) + fit_rows_kernel (leftovers) + slow_rows_kernel (declined rows)", tname<T>(), p.ws_stride / 64);
         if (pipe->before_first) (void)hipEventRecord(pipe->before_first, pipe->first);
         hipLaunchKernelGGL((wave_loo_kernel<T, VEC, false, CapsSmall, true, true>), dim3((unsigned)g1), dim3(kWave * kWavesPerBlock), 0,
                            pipe->first, p, f);
@@ -419,6 +435,8 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, co
           f.queue = pipe->sync;
           g1 = g1 < 512 ? g1 : 512;
         }
+        note_kernels("wave_loo_kernel<%s, SPLIT> (statistics, sweep, tail selection) + fit_rows_kernel<%d> (GPD fit, smoothing, "
+                     "outputs) + slow_rows_kernel (declined rows), back to back", tname<T>(), p.ws_stride / 64);
         hipLaunchKernelGGL((wave_loo_kernel<T, VEC, false, CapsSmall, true>), dim3((unsigned)g1), dim3(kWave * kWavesPerBlock), 0,
                            stream, p, f);
         e = hipGetLastError();
@@ -430,6 +448,7 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, co
     }
   }
   if (!split) {
+    note_kernels("wave_loo_kernel<%s%s> (fused: selection, fit and outputs in the wave) + slow_rows_kernel", tname<T>(), LW ? ", weights" : "");
     hipLaunchKernelGGL((wave_loo_kernel<T, VEC, LW, CapsSmall>), dim3((unsigned)grid), dim3(kWave * kWavesPerBlock), 0, stream, p, f);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -467,6 +486,9 @@ static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, int bits,
       f.ws_y = p.ws_y;
       f.ws_s = p.ws_s;
       f.ws_stride = p.ws_stride;
+      note_kernels("wave_loo_chunked_kernel<%s, SPLIT> (rows in chunks of 4096 draws: statistics, sweep, tail selection) + "
+                   "fit_rows_kernel<%d> (GPD fit, smoothing, outputs) + slow_rows_kernel (declined rows), back to back", tname<T>(),
+                   p.ws_stride / 64);
       hipLaunchKernelGGL((wave_loo_chunked_kernel<T, VEC, CAP, true>), dim3((unsigned)grid), dim3(kWave * W), 0, stream, p, f);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
@@ -475,6 +497,7 @@ static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, int bits,
       if (e != hipSuccess) return e;
     }
   } else {
+    note_kernels("wave_loo_chunked_kernel<%s%s> (fused) + slow_rows_kernel", tname<T>(), LW ? ", weights" : "");
     hipLaunchKernelGGL((wave_loo_chunked_kernel<T, VEC, CAP, false, LW>), dim3((unsigned)grid), dim3(kWave * W), 0, stream, p, f);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -500,6 +523,7 @@ static hipError_t launch_is(const RowsParams& p, hipStream_t stream) {
   FastParams f{0, 0, p.slow_list, p.counters, 0, nullptr, std::log((double)p.n_draws), nullptr, 0};
   int64_t grid = (p.n_obs + kWavesPerBlock - 1) / kWavesPerBlock;
   if (grid > 2048 * 8 / kWavesPerBlock) grid = 2048 * 8 / kWavesPerBlock;
+  note_kernels("is_wave_kernel<%s, %s%s> + slow_rows_kernel", tname<T>(), p.method == PLA_TIS ? "TIS" : "SIS", LW ? ", weights" : "");
   if (p.method == PLA_TIS)
     hipLaunchKernelGGL((is_wave_kernel<T, VEC, true, LW>), dim3((unsigned)grid), dim3(kWave * kWavesPerBlock), 0, stream, p, f);
   else
@@ -789,6 +813,39 @@ hipError_t launch_reduce(const ReduceParams& p, double* workspace, hipStream_t s
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(reduce_stage2, dim3(1), dim3(kWave), 0, stream, p, workspace, (int)chunks);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(kWave) void aggregate_pack_kernel(const double* agg, int rank, int world, double* table) {
+  for (int i = threadIdx.x; i < world * kRedSlots; i += kWave) table[i] = (i / kRedSlots == rank) ? agg[i % kRedSlots] : 0.0;
+}
+// (one lane: a rank count is a handful; the order of the merge is fixed, so every rank gets the same bits)
+__global__ __launch_bounds__(kWave) void aggregate_merge_kernel(const double* table, int world, double* out) {
+  if (threadIdx.x != 0) return;
+  Moments a{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, pinf()};
+  double n_slow = 0.0;
+  for (int r = 0; r < world; ++r) {
+    const double* o = table + (size_t)r * kRedSlots;
+    Moments b{o[PLA_AGG_N], o[PLA_AGG_N] > 0.0 ? o[PLA_AGG_SUM_LOO] / o[PLA_AGG_N] : 0.0, o[PLA_AGG_M2_LOO], o[PLA_AGG_SUM_LOO],
+              o[PLA_AGG_SUM_LPPD], o[PLA_AGG_N_HIGH], o[PLA_AGG_N_NONFINITE], o[PLA_AGG_MIN_DIAG]};
+    merge_moments(a, b);
+    n_slow += o[PLA_AGG_N_SLOW];
+  }
+  out[PLA_AGG_N] = a.n;
+  out[PLA_AGG_SUM_LOO] = a.s_loo;
+  out[PLA_AGG_M2_LOO] = a.m2;
+  out[PLA_AGG_SUM_LPPD] = a.s_lppd;
+  out[PLA_AGG_N_HIGH] = a.n_high;
+  out[PLA_AGG_N_NONFINITE] = a.n_bad;
+  out[PLA_AGG_MIN_DIAG] = a.dmin;
+  out[PLA_AGG_N_SLOW] = n_slow;
+}
+hipError_t launch_aggregate_pack(const double* agg, int rank, int world, double* table, hipStream_t stream) {
+  hipLaunchKernelGGL(aggregate_pack_kernel, dim3(1), dim3(kWave), 0, stream, agg, rank, world, table);
+  return hipGetLastError();
+}
+hipError_t launch_aggregate_merge(const double* table, int world, double* out, hipStream_t stream) {
+  hipLaunchKernelGGL(aggregate_merge_kernel, dim3(1), dim3(kWave), 0, stream, table, world, out);
   return hipGetLastError();
 }
 

@@ -374,6 +374,21 @@ class Engine:
         check(self._lib.pla_engine_first_kernel_ms(self._h, C.byref(ms), C.byref(k)))
         return ms.value, k.value
 
+    def last_kernels(self):
+        """Which kernels the last PSIS-LOO / weights call launched (text; for benchmark records)."""
+        buf = C.create_string_buffer(512)
+        check(self._lib.pla_engine_last_kernels(self._h, buf, 512))
+        return buf.value.decode("utf-8", "replace")
+
+    def aggregate_pack(self, agg, rank, world, table):
+        """``table`` (world x 8, this engine's device) = zeros except row ``rank`` = ``agg``: one kernel on the current stream."""
+        check(self._lib.pla_aggregate_pack(self._h, C.c_void_p(agg.data_ptr()), int(rank), int(world), C.c_void_p(table.data_ptr()),
+                                           self._stream()))
+
+    def aggregate_merge(self, table, world, out):
+        """``out`` (8) = the per-rank aggregate rows of ``table`` merged (Chan, Golub & LeVeque): one kernel on the current stream."""
+        check(self._lib.pla_aggregate_merge(self._h, C.c_void_p(table.data_ptr()), int(world), C.c_void_p(out.data_ptr()), self._stream()))
+
 
 def get_engine(device=None):
     """Process-wide engine for ``device`` (default: torch's current CUDA device, else 0)."""

@@ -74,6 +74,29 @@ def merge_moment_rows_tensor(table):
     return out
 
 
+_TABLES = {}  # (device, world) -> (table, out): allocated once, so that a timed step allocates nothing
+
+
+def all_reduce_aggregates_device(agg, engine, group=None):
+    """The multi-GPU step of a timed loop: ``agg`` is this rank's aggregate vector on the GPU; the merged vector comes back
+    as a CUDA tensor, identical on every rank.  One step is exactly: one pack kernel (``pla_aggregate_pack``: this rank's row
+    of a preallocated ``world x 8`` table, the other rows zero), ONE all-reduce of that table (RCCL over xGMI) and one merge
+    kernel (``pla_aggregate_merge``); nothing synchronises with the host and nothing is allocated."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    key = (agg.device, world)
+    if key not in _TABLES:
+        _TABLES[key] = (torch.zeros((world, AGG_COUNT), dtype=torch.float64, device=agg.device),
+                        torch.zeros(AGG_COUNT, dtype=torch.float64, device=agg.device))
+    table, out = _TABLES[key]
+    engine.aggregate_pack(agg, rank, world, table)
+    dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)  # the single collective
+    engine.aggregate_merge(table, world, out)
+    return out
+
+
 def all_reduce_aggregates(agg, group=None, as_tensor=False):
     """``agg``: this rank's aggregate vector (CUDA tensor, CPU tensor or ndarray).
     Returns the merged aggregate vector, identical on every rank: a NumPy array, or with ``as_tensor`` a

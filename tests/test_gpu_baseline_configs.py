@@ -148,6 +148,8 @@ def test_bench_launches_two_ranks(eng):
     out = _run_bench(["--gpus", "2", "--obs", str(n_local), "--steps", "2", "--warmup", "1", "--no-cpu"],
                      {"PYLOO_AMD_BENCH_BACKEND": "gloo", "PYLOO_AMD_BENCH_DEVICE": "0"})
     assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["backend"] == "gloo" and out["scaling"] == "weak"
+    assert out["devices_seen"] == [0, 0] and out["kernel_ms_per_rank"]["min"] <= out["kernel_ms_per_rank"]["max"]
+    assert "wave_loo_kernel" in out["roofline"]["kernels"]
     assert out["value"] > 0 and abs(out["value"] - 2 * n_local * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
     t = torch.empty((2 * n_local, S), dtype=torch.float64, device="cuda")
     eng.fill_synthetic(t, seed=0x5EED0003)  # rank r generated rows [r n_local, (r + 1) n_local) of this matrix
@@ -163,7 +165,7 @@ def test_rccl_all_reduce_world_size_one():
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, %r)
 from pyloo_amd.engine import get_engine
-from pyloo_amd.sharded import all_reduce_aggregates
+from pyloo_amd.sharded import all_reduce_aggregates, all_reduce_aggregates_device
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29617")
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
@@ -174,6 +176,9 @@ eng.fill_synthetic(t, seed=77)
 agg = eng.psis_loo(t, 190, "psis", 1.0, 0.7, pointwise=False)["agg"]
 merged = all_reduce_aggregates(agg, as_tensor=True)
 assert merged.is_cuda
+timed = all_reduce_aggregates_device(agg, eng)  # the step of the timed multi-GPU loop: pack kernel, all-reduce, merge kernel
+torch.cuda.synchronize()
+np.testing.assert_allclose(timed.cpu().numpy(), agg.cpu().numpy(), rtol=1e-13)
 host = all_reduce_aggregates(agg)
 torch.cuda.synchronize()
 a, m = agg.cpu().numpy(), merged.cpu().numpy()
@@ -185,6 +190,34 @@ print("rccl ok", a[1])
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     proc = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert proc.returncode == 0 and "rccl ok" in proc.stdout, proc.stdout[-1000:] + proc.stderr[-3000:]
+
+
+def test_aggregate_pack_and_merge_kernels(eng):
+    """`pla_aggregate_pack` / `pla_aggregate_merge` (one kernel each around the single all-reduce of a multi-GPU step): three
+    ranks' tables packed on one device and summed as the all-reduce would, merged, against the NumPy Chan merge."""
+    import torch
+
+    from pyloo_amd.sharded import merge_moment_rows
+
+    rng = np.random.default_rng(4)
+    x = rng.normal(-1e4, 0.1, size=9000)
+    rows = []
+    for lo, hi in ((0, 3000), (3000, 3000), (3000, 9000)):  # (the middle rank holds no observations)
+        c = x[lo:hi]
+        rows.append([c.size, c.sum(), np.sum((c - c.mean()) ** 2), 2 * c.sum(), c.size % 7, 1, c.min(), 2] if c.size else
+                    [0, 0, 0, 0, 0, 0, np.inf, 0])
+    world = len(rows)
+    total = torch.zeros((world, 8), dtype=torch.float64, device="cuda")
+    for r, row in enumerate(rows):
+        table = torch.full((world, 8), 7.0, dtype=torch.float64, device="cuda")  # (stale contents must not survive the pack)
+        eng.aggregate_pack(torch.tensor(row, dtype=torch.float64, device="cuda"), r, world, table)
+        total += table
+    out = torch.empty(8, dtype=torch.float64, device="cuda")
+    eng.aggregate_merge(total, world, out)
+    torch.cuda.synchronize()
+    want = merge_moment_rows(np.array(rows, dtype=np.float64))
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-13)
+    np.testing.assert_allclose(out[2].item() / x.size, np.var(x), rtol=1e-10)
 
 
 def test_device_path_runs_in_row_blocks(eng):

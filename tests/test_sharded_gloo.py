@@ -72,20 +72,30 @@ def test_bench_launches_its_own_ranks(monkeypatch):
     spec.loader.exec_module(bench)
     seen = {}
 
-    def fake_run(cmd, env=None, **kw):
-        seen["cmd"], seen["env"] = cmd, env
+    class FakeProc:
+        pid = 0
 
-        class R:
-            returncode = 7
+        def __init__(self, cmd, env=None, **kw):
+            seen["cmd"], seen["env"], seen["kw"] = cmd, env, kw
 
-        return R()
+        def wait(self, timeout=None):
+            seen["timeout"] = timeout
+            if seen.get("hang") and timeout is not None:
+                seen["hang"] = False
+                raise subprocess.TimeoutExpired(seen["cmd"], timeout)
+            return 7
 
-    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(os, "killpg", lambda pid, sig: seen.setdefault("killed", (pid, sig)))
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
     before = "torch" in sys.modules
     assert bench.main() == 7
     assert ("torch" in sys.modules) == before
+    assert seen["timeout"] and seen["kw"].get("start_new_session")  # bounded wait, a process group of its own
+    # a launch that never finishes: its process group is killed and the exit code is non-zero
+    seen["hang"] = True
+    assert bench.main() == 124 and "killed" in seen
     cmd = seen["cmd"]
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
@@ -149,3 +159,31 @@ def test_two_ranks_match_single_process(n_obs):
             np.testing.assert_allclose(v, want[key], rtol=1e-11, err_msg=f"rank {rank} {key}")
         sizes += n_local
     assert sizes == n_obs  # pointwise outputs stay sharded
+
+
+def test_default_node_run_is_labelled_c4(monkeypatch):
+    """`bench.py --gpus 8` with the default workload is BASELINE.json's C4: its label and its seed."""
+    import importlib.util
+    import subprocess
+
+    spec = importlib.util.spec_from_file_location("bench_under_test2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'args.config, args.seed = "C4", 0x5EED0004' in src
+    for key in ('"rccl_version"', '"devices_seen"', '"kernel_ms_per_rank"', '"host_cpu"', '"host_cores"'):
+        assert key in src, key
+    assert isinstance(bench.host_cpu_model(), str) and bench.host_cpu_model()
+    del subprocess
+
+
+def test_device_side_merge_kernel_contract():
+    """`pla_aggregate_pack` / `pla_aggregate_merge` are declared, exported and bound (one kernel each around the single
+    all-reduce of a timed multi-GPU step); their arithmetic is the Chan merge tested above, checked on the GPU in
+    tests/test_gpu_baseline_configs.py."""
+    from pyloo_amd import _capi
+
+    assert {"pla_aggregate_pack", "pla_aggregate_merge"} <= set(_capi.SYMBOLS)
+    lib = _capi.load_library()
+    assert lib.pla_aggregate_pack(None, None, 0, 1, None, None) < 0  # argument errors are status codes
+    assert lib.pla_aggregate_merge(None, None, 0, None, None) < 0
