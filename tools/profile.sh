@@ -52,14 +52,14 @@ for name, r in sorted(stats.items(), key=lambda kv: -float(kv[1]["TotalDurationN
     summary["kernels"][short] = {"calls": int(r["Calls"]), "avg_ms": avg, "avg_ms_timed": timed}
 lines += ["", "HBM traffic per launch (KiB counters x 1024; FETCH_SIZE doubled per MI355X_MICROARCH.md, HBM section):", ""]
 for name in fetch:
-    if "wave_loo" not in name and "rows_kernel" not in name: continue
+    if "wave_loo" not in name and "rows_kernel" not in name and "fit_rows" not in name: continue
     short = name.split("(")[0]
     f_kib = sorted(fetch[name])[len(fetch[name]) // 2]
     w_kib = sorted(write.get(name, [0.0]))[len(write.get(name, [0.0])) // 2]
     rd, wr = 2.0 * f_kib * 1024, w_kib * 1024
     lines.append(f"- {short}: FETCH_SIZE {f_kib:.0f} KiB -> read {rd/1e9:.3f} GB (corrected x2), WRITE_SIZE {w_kib:.0f} KiB -> write {wr/1e9:.4f} GB")
     summary["kernels"].setdefault(short, {}).update({"hbm_read_bytes": rd, "hbm_write_bytes": wr, "fetch_size_kib_raw": f_kib})
-main = [k for k in summary["kernels"] if ("wave_loo" in k or "rows_kernel" in k) and "hbm_read_bytes" in summary["kernels"][k]]
+main = [k for k in summary["kernels"] if ("wave_loo" in k or "rows_kernel" in k or "fit_rows" in k) and "hbm_read_bytes" in summary["kernels"][k]]
 if main:
     # the LOO pass is the wave kernel + the fit kernel + the general kernel over the declined rows: bench.py's roofline
     # times the whole pass, so the traffic is summed over its kernels too
