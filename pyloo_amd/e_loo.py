@@ -81,6 +81,23 @@ def _sample_last(a, what):
     return a, None, {}
 
 
+def _obs_dims(a):
+    return tuple(d for d in a.dims if d not in ("__sample__", "chain", "draw"))
+
+
+def _like(a, ref, what):
+    """``a`` with its observation dims in ``ref``'s order when both are DataArrays (same set of names, or ValueError)."""
+    if a is None or xr is None or not (isinstance(a, xr.DataArray) and isinstance(ref, xr.DataArray)):
+        return a
+    want, have = _obs_dims(ref), _obs_dims(a)
+    if set(want) != set(have):
+        raise ValueError(f"{what} has dims {tuple(a.dims)}, the data {tuple(ref.dims)}: the observation dims must have the same names")
+    if want == have:
+        return a
+    rest = tuple(d for d in a.dims if d not in have)
+    return a.transpose(*want, *rest)
+
+
 def _rows(a):
     return a.reshape(-1, a.shape[-1])
 
@@ -154,6 +171,10 @@ def e_loo(data, var_name=None, group="posterior_predictive", weights=None, log_w
             with np.errstate(divide="ignore"):
                 log_weights = np.log(np.asarray(weights))
     xv, dims, coords = _sample_last(x_data, "data")
+    # DataArrays pair up by dimension NAME (the reference aligns and broadcasts by name, e_loo.py:205-212): the weights and
+    # ratios are brought to the data's observation dims before their values are taken; other names are an error
+    log_weights = _like(log_weights, x_data, "log_weights")
+    log_ratios = _like(log_ratios, x_data, "log_ratios")
     lw, _, _ = _sample_last(log_weights, "log_weights")
     lr = None if log_ratios is None else _sample_last(log_ratios, "log_ratios")[0]
     if tuple(lw.shape) != tuple(xv.shape) or (lr is not None and tuple(lr.shape) != tuple(xv.shape)):
