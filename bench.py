@@ -100,6 +100,10 @@ def main():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0003)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--rows", default="iid", choices=["iid", "chain_ar1"],
+                    help="iid: BASELINE's generator (exchangeable draws).  chain_ar1: the same marginals as MCMC delivers them -- "
+                         "4 chains stacked chain-major, AR(1) with rho = 0.9 in the draw index, per-chain offsets (not a BASELINE "
+                         "config: what pl.loo(idata) rows look like to the speculative threshold)")
     ap.add_argument("--config", default=None, choices=["C2", "C3", "C4", "C5"],
                     help="BASELINE.json preset (per-GPU shard): C2 = 1e5 x 4000 f64, C3 / C4 = 1e6 x 4000 f64 per GPU, "
                          "C5 = 125 000 x 20 000 f32 per GPU with 30 %% heavy-tailed rows")
@@ -155,7 +159,11 @@ def main():
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
     esz = 8 if args.dtype == "f64" else 4
     ll = torch.empty((n_local, S), dtype=tdt, device=dev)
-    eng.fill_synthetic(ll, seed=args.seed, row0=rank * n_local, k_lo=0.05, k_hi=k_hi, heavy_lo=heavy[0], heavy_hi=heavy[1])
+    if args.rows == "chain_ar1":
+        eng.fill_synthetic_chains(ll, seed=args.seed, row0=rank * n_local, chains=4, rho=0.9, offset_sd=0.1, k_lo=0.05, k_hi=k_hi)
+        label += " rows as chain-major AR(1) chains (rho 0.9, 4 chains, per-chain offsets sd 0.1)"
+    else:
+        eng.fill_synthetic(ll, seed=args.seed, row0=rank * n_local, k_lo=0.05, k_hi=k_hi, heavy_lo=heavy[0], heavy_hi=heavy[1])
     torch.cuda.synchronize()
 
     reff = 1.0
@@ -243,6 +251,7 @@ def main():
             "seed": hex(args.seed),
             "elpd_loo": float(agg[1]),
             "n_high_k": int(agg[4]),
+            "rows_left_to_general_kernel": int(agg[7]),
         },
         "roofline": {
             "bound": "hbm",

@@ -253,6 +253,14 @@ int pla_fill_synthetic(pla_engine *eng, void *ll_device, int dtype, int64_t n_ob
                        int64_t row0, uint64_t seed, double k_lo, double k_hi, double heavy_lo,
                        double heavy_hi, void *stream);
 
+/* The same marginals as MCMC delivers them (bench.py --rows chain_ar1): `chains` chains stacked chain-major along the draws
+ * (the (chain, draw) -> __sample__ stack of loo.py:189), every chain a stationary AR(1) sequence in the draw index with
+ * coefficient rho (Gaussian copula, Exp(1) marginals), k_i ~ U(k_lo, k_hi) and c_i as above, plus an offset ~ N(0, offset_sd^2)
+ * of each chain's log-likelihoods. */
+int pla_fill_synthetic_chains(pla_engine *eng, void *ll_device, int dtype, int64_t n_obs, int64_t n_draws,
+                              int64_t row0, uint64_t seed, int chains, double rho, double offset_sd,
+                              double k_lo, double k_hi, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

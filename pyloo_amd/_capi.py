@@ -20,7 +20,7 @@ SYMBOLS = (
     "pla_tail_count", "pla_psis_loo", "pla_importance_weights", "pla_reduce_pointwise", "pla_waic",
     "pla_psis_loo_rows", "pla_waic_rows", "pla_e_loo", "pla_e_loo_quantiles",
     "pla_engine_set_frozen", "pla_engine_set_timing", "pla_engine_kernel_ms", "pla_engine_first_kernel_ms", "pla_fill_synthetic",
-    "pla_engine_last_kernels", "pla_aggregate_pack", "pla_aggregate_merge",
+    "pla_engine_last_kernels", "pla_aggregate_pack", "pla_aggregate_merge", "pla_fill_synthetic_chains",
 )
 
 
@@ -77,6 +77,7 @@ def load_library():
     lib.pla_engine_kernel_ms.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
     lib.pla_engine_first_kernel_ms.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
     lib.pla_fill_synthetic.argtypes = [vp, vp, ci, i64, i64, i64, C.c_uint64, dbl, dbl, dbl, dbl, vp]
+    lib.pla_fill_synthetic_chains.argtypes = [vp, vp, ci, i64, i64, i64, C.c_uint64, ci, dbl, dbl, dbl, dbl, vp]
     lib.pla_engine_last_kernels.argtypes = [vp, C.c_char_p, ci]
     lib.pla_aggregate_pack.argtypes = [vp, vp, ci, ci, vp, vp]
     lib.pla_aggregate_merge.argtypes = [vp, vp, ci, vp, vp]

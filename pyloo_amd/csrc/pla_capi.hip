@@ -1102,6 +1102,20 @@ int pla_e_loo_quantiles(pla_engine* eng, const void* x, const void* log_weights,
   return PLA_OK;
 }
 
+int pla_fill_synthetic_chains(pla_engine* eng, void* ll_device, int dtype, int64_t n_obs, int64_t n_draws, int64_t row0,
+                              uint64_t seed, int chains, double rho, double offset_sd, double k_lo, double k_hi, void* stream) {
+  if (!eng) return fail(PLA_ERR_ARG, "engine is NULL");
+  if (dtype != PLA_F64 && dtype != PLA_F32) return fail(PLA_ERR_ARG, "dtype must be PLA_F64 or PLA_F32");
+  if (n_obs < 0 || n_draws < 1) return fail(PLA_ERR_ARG, "bad shape");
+  if (chains < 1 || chains > n_draws) return fail(PLA_ERR_ARG, "need 1 <= chains <= n_draws");
+  if (!(rho > -1.0 && rho < 1.0) || !(offset_sd >= 0.0)) return fail(PLA_ERR_ARG, "need |rho| < 1 and offset_sd >= 0");
+  if (n_obs > 0 && !ll_device) return fail(PLA_ERR_ARG, "ll_device is NULL");
+  EngineCall call(eng);
+  PLA_HIP(hipSetDevice(eng->device));
+  PLA_HIP(pla::launch_fill_chains(ll_device, dtype, n_obs, n_draws, chains, rho, offset_sd, row0, seed, k_lo, k_hi, (hipStream_t)stream));
+  return PLA_OK;
+}
+
 int pla_fill_synthetic(pla_engine* eng, void* ll_device, int dtype, int64_t n_obs, int64_t n_draws, int64_t row0,
                        uint64_t seed, double k_lo, double k_hi, double heavy_lo, double heavy_hi, void* stream) {
   if (!eng) return fail(PLA_ERR_ARG, "engine is NULL");

@@ -24,9 +24,28 @@ namespace pla {
 
 constexpr int kChunkDraws = kWave * kWaveSlots;  // 4096
 
+// A long row is read ONCE, so its threshold can only know the first chunk -- exact for that chunk, blind to what later chains
+// of a chain-major stack do differently.  A row that ends with too few or too many draws above it is NOT handed to the general
+// kernel (twelve times the cost) but comes round a second time: the kernel's row loop schedules it again behind the row that
+// is already streaming in (one place where loads are issued, nothing waits), with the row's true maximum as the shift and a
+// threshold corrected by what the first attempt counted (ChunkRetry).
+struct ChunkRetry {
+  double t_raw;    // threshold on the raw scale
+  double m_raw;    // the row's maximum, known from the first attempt
+  int64_t row;     // -1: none
+  double t_prev;   // the attempt before: its threshold (raw scale) ...
+  double ln_prev;  // ... and the log of the number of draws that were above it
+  double lambda0;  // tail rate seen by the first attempt (first chunk)
+  int attempt;     // 0: a fresh row; kChunkAttempts - 1 is the last one
+};
+constexpr int kChunkAttempts = 4;
+
 template <typename T, int VEC, typename SM, typename TB, bool SPLIT = false, bool LW = false>
 __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const FastParams& F, SM& sm, const TB& tb,
-                                                    const int64_t r, T (&v)[kWaveSlots], const T* row, const T* rp_next) {
+                                                    const int64_t r, T (&v)[kWaveSlots], const T* row, const T* rp_next,
+                                                    const ChunkRetry& now, ChunkRetry& want) {
+  const bool second = now.attempt > 0;
+  const double t_second = now.t_raw, m_second = now.m_raw;
   constexpr int EPT = kWaveSlots;
   constexpr int NQ = EPT / VEC;
   constexpr int kCand = SM::Caps::kCand;
@@ -61,6 +80,8 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
   const unsigned lim8 = cand0 + 8u * kCand;
   unsigned next8 = cand0, base8 = cand0;
   const char* tabc = reinterpret_cast<const char*>(tb.tab);
+  bool thr_miss = false;  // lost to the threshold alone (as opposed to non-finite draws or the range)
+  unsigned c_first = 0;   // draws of the first chunk above the threshold
 
   wave_sync();  // previous row is done with the LDS scratch
   {
@@ -88,20 +109,34 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
       if (last) pad_tail<T, VEC, NQ - 1, true>(v, qfull, qrem, LW ? (T)mn_run : (T)(-mn_run));
       // speculative threshold from the first chunk's group maxima (see pla_wave.h); shift = its maximum
       mp = mc;
-      double lo = wave_all<R_MIN>(gs), hi = mc;
+      double hi = mc;
+      if (!second) {
+        double lo = wave_all<R_MIN>(gs);
 #pragma unroll 1
-      for (int it = 0; it < 9; ++it) {
-        const double mid = 0.5 * (lo + hi);
-        const int below = __popcll(__ballot(gs < mid));
-        if (below >= kq) hi = mid; else lo = mid;
-      }
-      if (mc - mnc < kWaveMaxRange) {
-        // (the exact counts look at this first chunk only: the rest of the row has not been read yet)
-        if (!wave_threshold_check<T, VEC, LW>(v, F, mnc, mc, hi)) slow = true;
+        for (int it = 0; it < 9; ++it) {
+          const double mid = 0.5 * (lo + hi);
+          const int below = __popcll(__ballot(gs < mid));
+          if (below >= kq) hi = mid; else lo = mid;
+        }
+        if (mc - mnc < kWaveMaxRange) {
+          // (the exact counts look at this first chunk only: the rest of the row has not been read yet)
+          if (!wave_threshold_check<T, VEC, LW>(v, F, mnc, mc, hi)) {
+            slow = true;
+            thr_miss = true;
+          }
+        }
+      } else {
+        // second attempt: the row's maximum is known (the shift is final from the start) and so is the threshold
+        mp = fmax(mc, m_second);
+        hi = t_second;
       }
       t1p = hi - mp;
-      if (!(t1p < 0.0)) slow = true;
+      if (!(t1p < 0.0)) {
+        slow = true;
+        thr_miss = true;
+      }
     }
+    if (ch == 1) c_first = (next8 - cand0) >> 3;
     // a non-finite maximum (inf / NaN draws) or a range that may overflow the sums: general kernel.
     // The chunk is still swept (clamped shift) so that the streaming of the following chunk goes on.
     if (!(m_run - mn_run < kWaveMaxRange)) slow = true;
@@ -190,10 +225,46 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
   // ---- the row maximum is known: candidates -> x, sums -> true shift ---------------------------------
   const double m = m_run, mn = mn_run, R = m - mn;
   const double delta = m - mp;  // >= 0
-  const unsigned ncand = (next8 - cand0) >> 3;
+  const unsigned ncand = (next8 - cand0) >> 3;  // (the true count, also past the list's capacity)
   double khat = INF, loo = 0.0, lppd = 0.0;
   wave_sync();
-  if (!slow && ((int)ncand < M + 1 || ncand > (unsigned)kCand)) slow = true;
+  if (nch == 1) c_first = ncand;
+  if (!slow && ((int)ncand < M + 1 || ncand > (unsigned)kCand)) {
+    slow = true;
+    if constexpr (!LW) {
+      if (now.attempt + 1 < kChunkAttempts && F.retry_target > 0 && c_first >= 8u && ncand >= 8u && R < kWaveMaxRange) {
+        // The next threshold, from EXACT counts of this row (dependence between neighbouring draws does not bias them) and an
+        // exponential tail, log count(t) = a - lambda t:
+        //   first return   the threshold t (relative to the first chunk's maximum, where one draw of that chunk lies) had c_first
+        //                  draws of the first chunk above it: lambda = log(c_first) / -t;
+        //   later returns  the secant through the last two attempts (t', n') and (t, n) -- the row's own tail, whatever its
+        //                  chains do (a chain that lies above the threshold as a whole saturates the first estimate).
+        //   a chain above the threshold as a whole (the count is several times the list, or did not move between two attempts):
+        //                  the threshold is anchored at the row's maximum instead, ln(target) / lambda below it -- where an
+        //                  exponential tail that ends in that maximum holds `target` draws.
+        const double t_now = mp + t1p, ln_now = log_fast((double)ncand), ln_tgt = log_fast((double)F.retry_target);
+        const double lambda0 = now.attempt > 0 ? now.lambda0 : log_fast((double)c_first) / -t1p;
+        double lambda = lambda0;
+        bool moved = true;
+        if (now.attempt > 0 && now.t_prev != t_now) {
+          const double sec = (now.ln_prev - ln_now) / (t_now - now.t_prev);
+          moved = fabs(now.ln_prev - ln_now) > 0.05;
+          if (sec > 0.0 && moved) lambda = sec;
+        }
+        double t_new = t_now + (ln_now - ln_tgt) / lambda;  // up when there were too many
+        if (ncand > 3u * (unsigned)kCand || !moved) t_new = fmax(t_new, m - ln_tgt / lambda0);
+        t_new = fmin(fmax(t_new, t_now - 3.0 * -t1p), m - 1e-3 * (m - mn));  // (stays below the row's maximum)
+        want.t_raw = t_new;
+        want.lambda0 = lambda0;
+        want.m_raw = m;
+        want.row = r;
+        want.t_prev = t_now;
+        want.ln_prev = ln_now;
+        want.attempt = now.attempt + 1;
+      }
+    }
+  }
+  (void)thr_miss;
   if (!slow) {
     for (unsigned c = lane; c < ncand; c += kWave) sm.cand[c] = LW ? sm.cand[c] - m : (-sm.cand[c]) - m;  // psis.py:134, one rounding
     s1 *= exp_tab(-delta, tb.tab);  // e^x = e^x' e^-(m - m');  s2 is rescaled in log space (lppd_shift)
@@ -237,7 +308,11 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
     if (rp_next) issue_row_loads<T, VEC, 0>(v, rp_next, S < kChunkDraws ? S : kChunkDraws);
   }
   if (lane == 0) {
-    if (slow) {
+    if (slow && want.row == r) {
+      // (comes round again: neither listed for the general kernel nor handed to the fit kernel -- a tail length of -1 in the
+      // hand-over until the second attempt overwrites it)
+      if constexpr (SPLIT) F.ws_s[r * F.ws_sstride + 5] = -1.0;
+    } else if (slow) {
       const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
       F.slow_list[idx] = (unsigned)r + F.slow_base;
       if constexpr (SPLIT) F.ws_s[r * F.ws_sstride + 5] = -1.0;  // tail length -1: on the list, nothing for the fit kernel
@@ -276,11 +351,34 @@ __global__ __launch_bounds__(kWave * CAP::kWaves, 1) void wave_loo_chunked_kerne
   const int first = P.n_draws < kChunkDraws ? P.n_draws : kChunkDraws;
   const T* cur = w0 < P.n_obs ? base + PLA_ROW_OFFSET(P, w0) : nullptr;
   if (cur) issue_row_loads<T, VEC>(v, cur, first);
-  for (int64_t r = w0; r < P.n_obs; r += nw) {
-    const int64_t rn = r + nw;
+  // the rows of this wave in order; a row that wants a second attempt is scheduled right behind the row that is already
+  // streaming in (that row's last sweep then streams the returning row's first chunk: ChunkRetry)
+  int64_t r = w0, fresh = w0 + nw;  // the row in hand, the next row not yet started
+  const ChunkRetry none{0.0, 0.0, -1, 0.0, 0.0, 0.0, 0};
+  ChunkRetry now = none, pending = none;
+  while (cur) {
+    // what follows the row in hand: a returning row first, else the next fresh one
+    const ChunkRetry after = pending.row >= 0 ? pending : none;
+    const int64_t rn = after.row >= 0 ? after.row : fresh;
+    if (after.row < 0) fresh += nw;
+    pending.row = -1;
     const T* nxt = rn < P.n_obs ? base + PLA_ROW_OFFSET(P, rn) : nullptr;
-    wave_loo_row_chunked<T, VEC, SM, TB, SPLIT, LW>(P, F, sm, tb, r, v, cur, nxt);
+    ChunkRetry want = none;
+    wave_loo_row_chunked<T, VEC, SM, TB, SPLIT, LW>(P, F, sm, tb, r, v, cur, nxt, now, want);
+    if (want.row >= 0) {
+      if (nxt) {
+        pending = want;  // behind the row that is streaming in
+      } else {
+        // (nothing is streaming in: this was the wave's last row.  It comes round at once -- its first chunk is requested
+        // here, the one other place of issue, which only the last row of a wave reaches)
+        issue_row_loads<T, VEC>(v, cur, first);
+        now = want;
+        continue;
+      }
+    }
     cur = nxt;
+    r = rn;
+    now = after;
   }
 }
 

@@ -83,6 +83,8 @@ const char* last_rows_kernels();
 // such a matrix (element (i, s) at in[s * stride_draw + i]) are written as a contiguous (n_rows, n_draws) block.
 hipError_t launch_transpose_rows(const void* in, int dtype, int64_t stride_draw, int64_t obs0, int64_t n_rows, int n_draws,
                                  void* out, hipStream_t stream);
+hipError_t launch_fill_chains(void* ll, int dtype, int64_t n_obs, int64_t n_draws, int chains, double rho, double off_sd, int64_t row0,
+                              uint64_t seed, double k_lo, double k_hi, hipStream_t stream);
 hipError_t launch_fill_synthetic(void* ll, int dtype, int64_t n_obs, int64_t n_draws, int64_t row0,
                                  uint64_t seed, double k_lo, double k_hi, double heavy_lo,
                                  double heavy_hi, hipStream_t stream);

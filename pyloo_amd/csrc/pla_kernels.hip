@@ -173,6 +173,40 @@ __global__ __launch_bounds__(256) void fill_kernel(T* ll, int64_t n_obs, int64_t
   }
 }
 
+// Synthetic rows as MCMC delivers them (bench.py --rows chain_ar1): `chains` chains stacked chain-major along the draws (the
+// (chain, draw) -> __sample__ stack of loo.py:189), every chain a stationary AR(1) sequence in the draw index -- z_t = rho z_{t-1}
+// + sqrt(1 - rho^2) eps_t, standard normal marginals -- mapped to Exp(1) marginals E = -log(1 - Phi(z)) and on to
+// ll = -k_i (E + o_ic / k_i ...) exactly as the iid generator does (same k_i, c_i), plus a per-chain offset o_ic ~ N(0, off_sd^2)
+// of the chain's log-likelihoods.  One thread per (observation, chain): the recursion is sequential in t.
+template <typename T>
+__global__ __launch_bounds__(256) void fill_chains_kernel(T* ll, int64_t n_obs, int64_t n_draws, int chains, double rho,
+                                                          double off_sd, int64_t row0, uint64_t seed, double k_lo, double k_hi) {
+  const int64_t total = n_obs * chains;
+  const int64_t per = n_draws / chains;
+  const double sd = sqrt(1.0 - rho * rho);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t il = e / chains;
+    const int c = (int)(e - il * chains);
+    const int64_t i = il + row0;
+    const double uk = u01_open(splitmix64(~seed ^ (uint64_t)i));
+    const double k = k_lo + (k_hi - k_lo) * uk;
+    const double ci = -1.0 - (double)(i % 7) * 0.25;
+    const auto normal = [&](uint64_t ctr) {  // Box-Muller on two counter-based uniforms
+      const double u1 = u01_open(splitmix64(seed ^ (2 * ctr))), u2 = u01_open(splitmix64(seed ^ (2 * ctr + 1)));
+      return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    };
+    const double off = off_sd * normal((uint64_t)(0x7000000000000000ull + (uint64_t)(i * chains + c)));
+    const int64_t t0 = c * per, t1 = (c == chains - 1) ? n_draws : t0 + per;
+    double z = normal((uint64_t)(i * n_draws + t0));
+    T* row = ll + il * n_draws;
+    for (int64_t t = t0; t < t1; ++t) {
+      if (t > t0) z = rho * z + sd * normal((uint64_t)(i * n_draws + t));
+      const double E = -log(0.5 * erfc(z * 0.7071067811865476));  // Exp(1) with the dependence of z
+      row[t] = (T)(-k * E + ci + off);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
@@ -474,6 +508,16 @@ static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, int bits,
   FastParams f{gsz, kq, p.slow_list, p.counters, 0, p.l1_table, std::log((double)p.n_draws), p.l1_table + p.tail_count, mestM};
   f.sample_bits = bits;
   f.cr_lo = chk.cr_lo; f.cr_hi = chk.cr_hi;
+  {
+    // second attempt of a row whose first-chunk threshold missed: the k-th smallest of its 64 x chunks per-lane chunk maxima
+    // (groups of 64 draws: a draw lies below it with probability F, F^64 = k / (64 chunks)) with ~PLA_CAND_MULT (M + 1) draws above
+    static const int no_retry = debug_flag("PLA_NO_RETRY");
+    const int nch = (p.n_draws + kChunkDraws - 1) / kChunkDraws;
+    const double Fq = 1.0 - PLA_CAND_MULT * (p.tail_count + 1) / (double)p.n_draws;
+    const int k = (int)std::lround(64.0 * nch * std::pow(Fq, 64.0));
+    f.retry_k = (!no_retry && nch > 1 && k >= 6 && k <= 32 * nch) ? k : 0;
+    f.retry_target = no_retry ? 0 : (int)(0.5 * ((p.tail_count + 1) + (double)CAP::kCand));  // the middle of what the list accepts
+  }
   constexpr int W = CAP::kWaves;  // waves per workgroup; two workgroups per CU (LDS)
   int64_t grid = (p.n_obs + W - 1) / W;
   if (grid > 2048 * 8 / W) grid = 2048 * 8 / W;
@@ -846,6 +890,20 @@ hipError_t launch_aggregate_pack(const double* agg, int rank, int world, double*
 }
 hipError_t launch_aggregate_merge(const double* table, int world, double* out, hipStream_t stream) {
   hipLaunchKernelGGL(aggregate_merge_kernel, dim3(1), dim3(kWave), 0, stream, table, world, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_fill_chains(void* ll, int dtype, int64_t n_obs, int64_t n_draws, int chains, double rho, double off_sd, int64_t row0,
+                              uint64_t seed, double k_lo, double k_hi, hipStream_t stream) {
+  if (n_obs <= 0 || n_draws <= 0) return hipSuccess;
+  const int64_t total = n_obs * chains;
+  const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  if (dtype == PLA_F64)
+    hipLaunchKernelGGL(fill_chains_kernel<double>, dim3(grid), dim3(256), 0, stream, (double*)ll, n_obs, n_draws, chains, rho, off_sd,
+                       row0, seed, k_lo, k_hi);
+  else
+    hipLaunchKernelGGL(fill_chains_kernel<float>, dim3(grid), dim3(256), 0, stream, (float*)ll, n_obs, n_draws, chains, rho, off_sd,
+                       row0, seed, k_lo, k_hi);
   return hipGetLastError();
 }
 

@@ -355,6 +355,16 @@ class Engine:
         check(self._lib.pla_fill_synthetic(self._h, C.c_void_p(t.data_ptr()), code, n, s, int(row0), int(seed),
                                            k_lo, k_hi, heavy_lo, heavy_hi, self._stream()))
 
+    def fill_synthetic_chains(self, t, seed, row0=0, chains=4, rho=0.9, offset_sd=0.3, k_lo=0.05, k_hi=0.60):
+        """Rows as MCMC delivers them: chain-major stack of AR(1) chains with per-chain offsets (``pla_fill_synthetic_chains``)."""
+        import torch
+
+        code = _capi.PLA_F64 if t.dtype == torch.float64 else _capi.PLA_F32
+        n, s = t.shape
+        assert t.is_contiguous()
+        check(self._lib.pla_fill_synthetic_chains(self._h, C.c_void_p(t.data_ptr()), code, n, s, int(row0), int(seed), int(chains),
+                                                  float(rho), float(offset_sd), k_lo, k_hi, self._stream()))
+
     def set_frozen(self, on):
         """Frozen: calls that would reallocate engine workspace fail (EngineError -6) instead of invalidating the
         raw pointers a captured HIP graph holds (include/pyloo_amd.h, "HIP graphs")."""

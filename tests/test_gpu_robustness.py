@@ -82,8 +82,10 @@ CASES = [
     ("chains_ar1", 2000, np.float64, 0.002),
     # long rows are read ONCE in chunks of 4096 draws, so the threshold can only know the first chunk: exact for that
     # chunk (autocorrelation inside it no longer matters: 79 % -> 3 %), blind to what later chains do differently
-    ("ar1", 20000, np.float32, 0.06),
-    ("chains_ar1", 8000, np.float64, 0.30),
+    # ... and a row that ends with too few / too many draws above it comes round a second time with a threshold corrected by
+    # the first attempt's exact counts (pla_chunked.h, ChunkRetry): 4.5 % -> 0.2 % and 15.8 % -> 1.9 % (measured, round 3)
+    ("ar1", 20000, np.float32, 0.01),
+    ("chains_ar1", 8000, np.float64, 0.03),
 ]
 
 
@@ -95,10 +97,11 @@ def test_order_of_the_draws(eng, kind, S, dt, bound):
     M = orc.tail_count(S, 1.0)
     res = eng.psis_loo(ll, M, "psis", 1.0, 0.7)
     frac = res["agg"][7] / n
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", os.environ.get("PLA_HANDOVER_LOG", "handover_rates.jsonl")), "a") as f:
-        f.write(json.dumps({"kind": kind, "S": S, "dtype": np.dtype(dt).name, "rows": n, "handed_over": float(res["agg"][7]),
-                            "fraction": float(frac)}) + "\n")
+    if os.environ.get("PLA_HANDOVER_LOG"):  # (a record for profiles/, only when asked for: no side effects otherwise)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", os.environ["PLA_HANDOVER_LOG"]), "a") as f:
+            f.write(json.dumps({"kind": kind, "S": S, "dtype": np.dtype(dt).name, "rows": n, "handed_over": float(res["agg"][7]),
+                                "fraction": float(frac)}) + "\n")
     idx = np.arange(0, n, 15)
     ref = orc.loo_arrays(ll[idx].astype(np.float64), 1.0)
     close(res["diag"][idx], ref["khat"], what="khat")
