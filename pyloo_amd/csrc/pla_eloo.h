@@ -610,8 +610,94 @@ __device__ __forceinline__ bool mass_select(Each each, const double target, doub
   return true;
 }
 
+// The same selection from ONE histogram of the row shared by every level asked for: kQBins bins, linear in x between the
+// row's extremes, filled once (weights, or counts for np.quantile's branch) and turned into running sums; a level then costs a
+// parallel look-up of its bin, one trip over the draws held in registers to collect that bin's members (a handful) and the
+// settling of that list -- instead of two or three radix passes of one LDS atomic per draw EACH (4000 atomics a pass).
+// Returns 1: found; 0: the total never reaches the target; -1: more than 256 draws share the bin (very uneven rows: the caller
+// falls back to the radix descent above).
+constexpr int kQBins = 2048;
+__device__ __forceinline__ int qbin_of(double x, double x0, double scale) {
+  const int b = (int)((x - x0) * scale);
+  return b < 0 ? 0 : (b > kQBins - 1 ? kQBins - 1 : b);
+}
+template <int BLOCK, class Each>
+__device__ __forceinline__ int hist_select(Each each, const double target, const double* cum, const double x0, const double scale,
+                                           double* red, QuantList* ql, uint64_t* key_out, double* below, double* at) {
+  const int tid = threadIdx.x;
+  constexpr int PER = kQBins / BLOCK;
+  if (tid == 0) {
+    red[1] = -1.0;
+    ql->count = 0;
+    ql->best = ~0ull;
+  }
+  __syncthreads();
+  {  // the bin in which the running sum first reaches the target (exactly one thread finds it)
+    double prev = tid == 0 ? 0.0 : cum[tid * PER - 1];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const double c = cum[tid * PER + i];
+      if (prev < target && c >= target) {
+        red[0] = prev;
+        red[1] = (double)(tid * PER + i);
+      }
+      prev = c;
+    }
+  }
+  __syncthreads();
+  const int tb = (int)red[1];
+  const double base = red[0];
+  __syncthreads();
+  if (tb < 0) return 0;
+  each([&](const uint64_t k, const double mass) {
+    if (qbin_of(val_of(k), x0, scale) == tb) {
+      const int idx = atomicAdd(&ql->count, 1);
+      if (idx < 256) {
+        ql->key[idx] = k;
+        ql->mass[idx] = mass;
+      }
+    }
+  });
+  __syncthreads();
+  const int n = ql->count;
+  if (n > 256) return -1;
+  uint64_t mine = ~0ull;
+  double upto = base, under = base;
+  if (tid < n) {
+    mine = ql->key[tid];
+    for (int j = 0; j < n; ++j) {
+      const uint64_t kj = ql->key[j];
+      const double mj = ql->mass[j];
+      upto += (kj <= mine) ? mj : 0.0;
+      under += (kj < mine) ? mj : 0.0;
+    }
+  }
+  const bool reaches = tid < n && upto >= target;
+  if (reaches) atomicMin(&ql->best, (unsigned long long)mine);
+  __syncthreads();
+  const uint64_t best = (uint64_t)ql->best;
+  if (best == ~0ull) return -1;  // (rounding at the bin's edge: let the radix descent decide)
+  if (reaches && mine == best) {  // (equal draws compute the same two numbers)
+    red[0] = under;
+    red[2] = upto - under;
+  }
+  __syncthreads();
+  *key_out = best;
+  *below = red[0];
+  *at = red[2];
+  __syncthreads();
+  return 1;
+}
+
 template <typename T, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
+  __shared__ __attribute__((aligned(32))) double cum2k[kQBins];
+  __shared__ __attribute__((aligned(32))) double scan[BLOCK];
+  __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];  // table-driven exponential (pla_math.h): a third of libm's registers
+  for (int j = threadIdx.x; j < kTabN; j += BLOCK) exp_table_entry(tab, j);
+  __syncthreads();
+  // w = e^(lw - max lw); a NaN weight or a non-finite maximum makes every weight NaN in the reference (the sum is poisoned below)
+  const auto wexp = [&](double d) { return exp_tab(fmax(d, -700.0), tab); };
   __shared__ __attribute__((aligned(32))) double hist[256];
   __shared__ double red[BLOCK / kWave > 4 ? BLOCK / kWave : 4];
   __shared__ QuantList qlist;
@@ -627,7 +713,7 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
     // (up to kKeep per thread: S <= 4096 at 256 threads; longer rows re-read and re-evaluate): ONE trip over the two rows with
     // all its loads in flight together and one exponential per draw, then LDS atomics only -- instead of four trips with
     // dependent loads before the first radix pass and an exponential and a division per draw in every pass after it.
-    constexpr int kKeep = 16;
+    constexpr int kKeep = 4096 / BLOCK;  // (512 threads: 8 draws each -- the kernel then fits four waves per SIMD)
     const bool kept = S <= kKeep * BLOCK;
     uint64_t kreg[kKeep];
     double wreg[kKeep];
@@ -657,14 +743,16 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
       nanw = block_or_bits<BLOCK>(nanw, red);
 #pragma unroll
       for (int j = 0; j < kKeep; ++j) {
-        wreg[j] = tid + j * BLOCK < S ? exp(wreg[j] - mlw) : 0.0;
+        wreg[j] = tid + j * BLOCK < S ? wexp(wreg[j] - mlw) : 0.0;
         sa += wreg[j];
       }
       sa = block_reduce<OpSum, BLOCK>(sa, red);
-      w0 = exp((double)wr[0] - mlw) / sa;
+      if (nanw || !(fabs(mlw) < pinf())) sa = qnan();
+      const double inv_sa = 1.0 / sa;
+      w0 = wexp((double)wr[0] - mlw) * inv_sa;
 #pragma unroll
       for (int j = 0; j < kKeep; ++j) {
-        wreg[j] = wreg[j] / sa;
+        wreg[j] = wreg[j] * inv_sa;
         dev = tid + j * BLOCK < S ? fmax(dev, fabs(wreg[j] - w0)) : dev;
       }
       dev = block_reduce<OpMax, BLOCK>(dev, red);
@@ -681,14 +769,15 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
       xmax = block_reduce<OpMax, BLOCK>(xmax, red);
       xmin = block_reduce<OpMin, BLOCK>(xmin, red);
       nanw = block_or_bits<BLOCK>(nanw, red);
-      for (int s = tid; s < S; s += BLOCK) sa += exp((double)wr[(int64_t)s * P.stride_draw] - mlw);
+      for (int s = tid; s < S; s += BLOCK) sa += wexp((double)wr[(int64_t)s * P.stride_draw] - mlw);
       sa = block_reduce<OpSum, BLOCK>(sa, red);
-      w0 = exp((double)wr[0] - mlw) / sa;
-      for (int s = tid; s < S; s += BLOCK) dev = fmax(dev, fabs(exp((double)wr[(int64_t)s * P.stride_draw] - mlw) / sa - w0));
+      if (nanw || !(fabs(mlw) < pinf())) sa = qnan();
+      w0 = wexp((double)wr[0] - mlw) / sa;
+      for (int s = tid; s < S; s += BLOCK) dev = fmax(dev, fabs(wexp((double)wr[(int64_t)s * P.stride_draw] - mlw) / sa - w0));
       dev = block_reduce<OpMax, BLOCK>(dev, red);
     }
     const bool flat = !nanw && dev <= kCloseAtol + kCloseRtol * fabs(w0);                 // e_loo.py:536
-    const auto wat = [&](int s) { return exp((double)wr[(int64_t)s * P.stride_draw] - mlw) / sa; };
+    const auto wat = [&](int s) { return wexp((double)wr[(int64_t)s * P.stride_draw] - mlw) / sa; };
     const auto each = [&](auto f) {  // f(key, weight) for every draw of this thread
       if (kept) {
 #pragma unroll
@@ -713,6 +802,48 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
       each([&](const uint64_t, const double w) { wtot += w; });
       wtot = block_reduce<OpSum, BLOCK>(wtot, red);                                       // e_loo.py:542: cumsum / sum
     }
+    // one histogram of the row for every level (hist_select): rows kept in registers with finite, distinct extremes
+    const bool hist_ok = kept && xmax > xmin && xmax - xmin < 1e300 && xmin > -1e300;
+    const double qscale = hist_ok ? (double)kQBins / (xmax - xmin) : 0.0;
+    if (hist_ok) {
+      for (int i = tid; i < kQBins; i += BLOCK) cum2k[i] = 0.0;
+      __syncthreads();
+      each([&](const uint64_t k, const double w) { atomicAdd(&cum2k[qbin_of(val_of(k), xmin, qscale)], flat ? 1.0 : w); });
+      __syncthreads();
+      // running sums in place: each thread its kQBins / BLOCK bins, a block scan of the thread totals in between
+      constexpr int PER = kQBins / BLOCK;
+      double loc[PER], run = 0.0;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        run += cum2k[tid * PER + i];
+        loc[i] = run;
+      }
+      scan[tid] = run;
+      __syncthreads();
+      if (tid < kWave) {  // exclusive scan of the BLOCK thread totals by the first wave, BLOCK / 64 per lane
+        constexpr int Q = BLOCK / kWave;
+        double part[Q], tot = 0.0;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+          part[i] = tot;
+          tot += scan[Q * tid + i];
+        }
+        double incl = tot;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+          const double up = __shfl_up(incl, o, kWave);
+          if (tid >= o) incl += up;
+        }
+        const double before = incl - tot;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) scan[Q * tid + i] = before + part[i];
+      }
+      __syncthreads();
+      const double off = scan[tid];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) cum2k[tid * PER + i] = off + loc[i];
+      __syncthreads();
+    }
     for (int ip = 0; ip < P.n_probs; ++ip) {
       const double prob = P.probs[ip];
       double res;
@@ -722,7 +853,8 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
         // np.quantile(x, prob), method "linear": virtual index (S - 1) prob between the order statistics lo and lo + 1
         const double virt = (double)(S - 1) * prob;
         const double lo = floor(virt), t = virt - lo;
-        mass_select<BLOCK>(each_count, lo + 1.0, hist, red, &qlist, &kv, &below, &at);
+        int hs = hist_ok ? hist_select<BLOCK>(each_count, lo + 1.0, cum2k, xmin, qscale, red, &qlist, &kv, &below, &at) : -1;
+        if (hs < 0) mass_select<BLOCK>(each_count, lo + 1.0, hist, red, &qlist, &kv, &below, &at);
         const double a = val_of(kv);
         double b = a;
         if (below + at < lo + 2.0 && lo + 1.0 < (double)S) {  // the next order statistic is the next distinct value
@@ -736,7 +868,8 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
         res = (t >= 0.5) ? b - diff * (1.0 - t) : a + diff * t;                           // numpy's _lerp
         if (t == 0.0) res = a;
       } else {
-        const bool found = mass_select<BLOCK>(each, prob * wtot, hist, red, &qlist, &kv, &below, &at);
+        const int hs = hist_ok ? hist_select<BLOCK>(each, prob * wtot, cum2k, xmin, qscale, red, &qlist, &kv, &below, &at) : -1;
+        const bool found = hs >= 0 ? hs == 1 : mass_select<BLOCK>(each, prob * wtot, hist, red, &qlist, &kv, &below, &at);
         if (!found) {
           res = xmax;                                                                     // 545-546
         } else {

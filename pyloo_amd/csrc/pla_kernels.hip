@@ -832,8 +832,10 @@ hipError_t launch_e_loo_quantiles(const void* x, const void* lw, int dtype, int6
   if (n_obs <= 0 || n_probs <= 0) return hipSuccess;
   EQuantParams p{x, lw, n_obs, n_draws, stride_obs, stride_draw, probs, n_probs, out};
   const int64_t grid = n_obs < 16384 ? n_obs : 16384;
-  if (dtype == PLA_F64) hipLaunchKernelGGL((e_loo_quantile_kernel<double, 256>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((e_loo_quantile_kernel<float, 256>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+  // (512 threads per observation: eight draws per thread in registers instead of sixteen -- 104 registers, four waves per SIMD,
+  // where 256 threads needed 260 and ran one workgroup per CU)
+  if (dtype == PLA_F64) hipLaunchKernelGGL((e_loo_quantile_kernel<double, 512>), dim3((unsigned)grid), dim3(512), 0, stream, p);
+  else hipLaunchKernelGGL((e_loo_quantile_kernel<float, 512>), dim3((unsigned)grid), dim3(512), 0, stream, p);
   return hipGetLastError();
 }
 
