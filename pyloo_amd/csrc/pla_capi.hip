@@ -1072,7 +1072,10 @@ int pla_e_loo_quantiles(pla_engine* eng, const void* x, const void* log_weights,
   PLA_HIP(hipStreamSynchronize(s));  // (the caller's probs array may go away after the call)
   const double* dp = (const double*)eng->d_probs;
   if (mem_space == PLA_DEVICE) {
-    PLA_HIP(pla::launch_e_loo_quantiles(x, log_weights, dtype, n_obs, (int)n_draws, stride_obs, stride_draw, dp, (int)n_probs, out, s));
+    rc = grow(&eng->d_slow, &eng->d_slow_bytes, (size_t)n_obs * sizeof(unsigned));
+    if (rc) return rc;
+    PLA_HIP(pla::launch_e_loo_quantiles(x, log_weights, dtype, n_obs, (int)n_draws, stride_obs, stride_draw, dp, (int)n_probs, out,
+                                        (unsigned*)eng->d_slow, eng->counters, s));
     return PLA_OK;
   }
   if (stride_draw != 1) return fail(PLA_ERR_UNSUPPORTED, "PLA_HOST input needs stride_draw == 1");
@@ -1090,12 +1093,15 @@ int pla_e_loo_quantiles(pla_engine* eng, const void* x, const void* log_weights,
     eng->d_pw_elems = have_b / sizeof(double);
     if (rc) return rc;
   }
+  rc = grow(&eng->d_slow, &eng->d_slow_bytes, (size_t)rows_per_chunk * sizeof(unsigned));
+  if (rc) return rc;
   for (int64_t r0 = 0; r0 < n_obs; r0 += rows_per_chunk) {
     const int64_t nr = (n_obs - r0 < rows_per_chunk) ? (n_obs - r0) : rows_per_chunk;
     const size_t off = (size_t)r0 * stride_obs * esz, pitch = (size_t)stride_obs * esz;
     PLA_HIP(hipMemcpy2DAsync(eng->d_in, row_bytes, (const char*)x + off, pitch, row_bytes, (size_t)nr, hipMemcpyHostToDevice, s));
     PLA_HIP(hipMemcpy2DAsync(eng->d_lw, row_bytes, (const char*)log_weights + off, pitch, row_bytes, (size_t)nr, hipMemcpyHostToDevice, s));
-    PLA_HIP(pla::launch_e_loo_quantiles(eng->d_in, eng->d_lw, dtype, nr, (int)n_draws, n_draws, 1, dp, (int)n_probs, eng->d_pw, s));
+    PLA_HIP(pla::launch_e_loo_quantiles(eng->d_in, eng->d_lw, dtype, nr, (int)n_draws, n_draws, 1, dp, (int)n_probs, eng->d_pw,
+                                        (unsigned*)eng->d_slow, eng->counters, s));
     PLA_HIP(hipMemcpyAsync(out + r0 * n_probs, eng->d_pw, (size_t)(nr * n_probs) * sizeof(double), hipMemcpyDeviceToHost, s));
     PLA_HIP(hipStreamSynchronize(s));
   }

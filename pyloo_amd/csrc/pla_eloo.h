@@ -489,6 +489,10 @@ struct EQuantParams {
   const double* probs;  // [n_probs] device
   int n_probs;
   double* out;          // [n_obs][n_probs]
+  // FAST variant: rows it does not take (non-finite or constant draws, more than 256 draws in a level's histogram bin) are
+  // listed here and redone by the general variant, which walks the list when one is given
+  unsigned* slow_list = nullptr;
+  unsigned long long* slow_count = nullptr;
 };
 
 // smallest key whose cumulative mass (sum of the masses of the draws with key <= it) reaches `target`; *below = mass strictly
@@ -616,6 +620,41 @@ __device__ __forceinline__ bool mass_select(Each each, const double target, doub
 // settling of that list -- instead of two or three radix passes of one LDS atomic per draw EACH (4000 atomics a pass).
 // Returns 1: found; 0: the total never reaches the target; -1: more than 256 draws share the bin (very uneven rows: the caller
 // falls back to the radix descent above).
+// NS sums and NM maxima over the workgroup in ONE LDS exchange (two barriers whatever NS + NM): what this kernel costs are its
+// block-wide reductions (~1.5 us each), a dozen per row and level when every value goes round by itself.  `lds`: (NS + NM)
+// doubles per wave.  Maxima ignore NaN (callers flag NaN separately); a minimum goes in negated.
+template <int NS, int NM, int BLOCK>
+__device__ __forceinline__ void block_reduce_mix(double (&sv)[NS > 0 ? NS : 1], double (&mv)[NM > 0 ? NM : 1], double* lds) {
+  constexpr int NW = BLOCK / kWave, N = NS + NM;
+  const int w = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const double r = wave_all<R_SUM>(sv[i]);
+    if (lane == 0) lds[w * N + i] = r;
+  }
+#pragma unroll
+  for (int i = 0; i < NM; ++i) {
+    const double r = wave_all<R_MAX>(mv[i]);
+    if (lane == 0) lds[w * N + NS + i] = r;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) a += lds[k * N + i];
+    sv[i] = a;
+  }
+#pragma unroll
+  for (int i = 0; i < NM; ++i) {
+    double a = lds[NS + i];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) a = fmax(a, lds[k * N + NS + i]);
+    mv[i] = a;
+  }
+  __syncthreads();
+}
+
 constexpr int kQBins = 2048;
 __device__ __forceinline__ int qbin_of(double x, double x0, double scale) {
   const int b = (int)((x - x0) * scale);
@@ -689,8 +728,10 @@ __device__ __forceinline__ int hist_select(Each each, const double target, const
   return 1;
 }
 
-template <typename T, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
+// FAST: the histogram path only (no radix descent in the code: 60 registers less, two workgroups per CU instead of one, so
+// that one workgroup's barriers are another one's issue slots); GENERAL (FAST = false): everything, over the rows FAST listed.
+template <typename T, int BLOCK, bool FAST = false>
+__global__ __launch_bounds__(BLOCK, FAST ? 4 : 1) void e_loo_quantile_kernel(EQuantParams P) {
   __shared__ __attribute__((aligned(32))) double cum2k[kQBins];
   __shared__ __attribute__((aligned(32))) double scan[BLOCK];
   __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];  // table-driven exponential (pla_math.h): a third of libm's registers
@@ -700,10 +741,14 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
   const auto wexp = [&](double d) { return exp_tab(fmax(d, -700.0), tab); };
   __shared__ __attribute__((aligned(32))) double hist[256];
   __shared__ double red[BLOCK / kWave > 4 ? BLOCK / kWave : 4];
+  __shared__ double mix[4 * (BLOCK / kWave)];
   __shared__ QuantList qlist;
   const int tid = threadIdx.x;
   const int S = P.n_draws;
-  for (int64_t r = blockIdx.x; r < P.n_obs; r += gridDim.x) {
+  const int64_t n_rows = (!FAST && P.slow_list) ? (int64_t)*P.slow_count : P.n_obs;
+  for (int64_t ri = blockIdx.x; ri < n_rows; ri += gridDim.x) {
+    const int64_t r = (!FAST && P.slow_list) ? (int64_t)P.slow_list[ri] : ri;
+    bool declined = false;  // (FAST: this row goes on the list)
     const T* xr = reinterpret_cast<const T*>(P.x) + r * P.stride_obs;
     const T* wr = reinterpret_cast<const T*>(P.lw) + r * P.stride_obs;
     const auto xat = [&](int s) { return (double)xr[(int64_t)s * P.stride_draw]; };
@@ -717,7 +762,7 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
     const bool kept = S <= kKeep * BLOCK;
     uint64_t kreg[kKeep];
     double wreg[kKeep];
-    double mlw = -pinf(), xmax = -pinf(), xmin = pinf(), sa = 0.0, dev = 0.0, w0;
+    double mlw = -pinf(), xmax = -pinf(), xmin = pinf(), sa = 0.0, dev = 0.0, w0, wtot_kept = 0.0;
     unsigned nanw = 0;
     if (kept) {
       double xv[kKeep];
@@ -737,10 +782,11 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
         xmin = in ? fmin(xmin, xv[j]) : xmin;
         kreg[j] = in ? key_of(xv[j]) : ~0ull;
       }
-      mlw = block_reduce<OpMax, BLOCK>(mlw, red);
-      xmax = block_reduce<OpMax, BLOCK>(xmax, red);
-      xmin = block_reduce<OpMin, BLOCK>(xmin, red);
-      nanw = block_or_bits<BLOCK>(nanw, red);
+      {
+        double none[1] = {0.0}, mx4[4] = {mlw, xmax, -xmin, nanw ? 1.0 : 0.0};
+        block_reduce_mix<0, 4, BLOCK>(none, mx4, mix);
+        mlw = mx4[0]; xmax = mx4[1]; xmin = -mx4[2]; nanw = mx4[3] > 0.0 ? 1u : 0u;
+      }
 #pragma unroll
       for (int j = 0; j < kKeep; ++j) {
         wreg[j] = tid + j * BLOCK < S ? wexp(wreg[j] - mlw) : 0.0;
@@ -750,12 +796,19 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
       if (nanw || !(fabs(mlw) < pinf())) sa = qnan();
       const double inv_sa = 1.0 / sa;
       w0 = wexp((double)wr[0] - mlw) * inv_sa;
+      double wsum = 0.0;
 #pragma unroll
       for (int j = 0; j < kKeep; ++j) {
         wreg[j] = wreg[j] * inv_sa;
         dev = tid + j * BLOCK < S ? fmax(dev, fabs(wreg[j] - w0)) : dev;
+        wsum += tid + j * BLOCK < S ? wreg[j] : 0.0;
       }
-      dev = block_reduce<OpMax, BLOCK>(dev, red);
+      {  // the largest deviation from the first weight and the sum of the normalised weights (e_loo.py:542) in one exchange
+        double s1[1] = {wsum}, m1[1] = {dev};
+        block_reduce_mix<1, 1, BLOCK>(s1, m1, mix);
+        wtot_kept = s1[0];
+        dev = m1[0];
+      }
     } else {
       for (int s = tid; s < S; s += BLOCK) {
         const double a = (double)wr[(int64_t)s * P.stride_draw];
@@ -797,14 +850,17 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
         for (int s = tid; s < S; s += BLOCK) f(key_at(s), wat(s), s);
       }
     };
-    double wtot = 0.0;
-    if (!flat) {
+    double wtot = wtot_kept;
+    if (!flat && !kept) {
       each([&](const uint64_t, const double w) { wtot += w; });
       wtot = block_reduce<OpSum, BLOCK>(wtot, red);                                       // e_loo.py:542: cumsum / sum
     }
     // one histogram of the row for every level (hist_select): rows kept in registers with finite, distinct extremes
     const bool hist_ok = kept && xmax > xmin && xmax - xmin < 1e300 && xmin > -1e300;
     const double qscale = hist_ok ? (double)kQBins / (xmax - xmin) : 0.0;
+    if constexpr (FAST) {
+      if (!hist_ok) declined = true;
+    }
     if (hist_ok) {
       for (int i = tid; i < kQBins; i += BLOCK) cum2k[i] = 0.0;
       __syncthreads();
@@ -844,7 +900,7 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
       for (int i = 0; i < PER; ++i) cum2k[tid * PER + i] = off + loc[i];
       __syncthreads();
     }
-    for (int ip = 0; ip < P.n_probs; ++ip) {
+    for (int ip = 0; ip < P.n_probs && !declined; ++ip) {
       const double prob = P.probs[ip];
       double res;
       uint64_t kv = 0;
@@ -854,7 +910,14 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
         const double virt = (double)(S - 1) * prob;
         const double lo = floor(virt), t = virt - lo;
         int hs = hist_ok ? hist_select<BLOCK>(each_count, lo + 1.0, cum2k, xmin, qscale, red, &qlist, &kv, &below, &at) : -1;
-        if (hs < 0) mass_select<BLOCK>(each_count, lo + 1.0, hist, red, &qlist, &kv, &below, &at);
+        if constexpr (FAST) {
+          if (hs < 0) {
+            declined = true;
+            break;
+          }
+        } else {
+          if (hs < 0) mass_select<BLOCK>(each_count, lo + 1.0, hist, red, &qlist, &kv, &below, &at);
+        }
         const double a = val_of(kv);
         double b = a;
         if (below + at < lo + 2.0 && lo + 1.0 < (double)S) {  // the next order statistic is the next distinct value
@@ -869,26 +932,36 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
         if (t == 0.0) res = a;
       } else {
         const int hs = hist_ok ? hist_select<BLOCK>(each, prob * wtot, cum2k, xmin, qscale, red, &qlist, &kv, &below, &at) : -1;
-        const bool found = hs >= 0 ? hs == 1 : mass_select<BLOCK>(each, prob * wtot, hist, red, &qlist, &kv, &below, &at);
+        bool found = hs == 1;
+        if constexpr (FAST) {
+          if (hs < 0) {
+            declined = true;
+            break;
+          }
+        } else {
+          if (hs < 0) found = mass_select<BLOCK>(each, prob * wtot, hist, red, &qlist, &kv, &below, &at);
+        }
         if (!found) {
           res = xmax;                                                                     // 545-546
         } else {
           const double v = val_of(kv);
           double prev = -pinf();
-          each([&](const uint64_t k, const double) {
+          double sfirst = 1e300;
+          each_s([&](const uint64_t k, const double, const int si) {
             if (k < kv) prev = fmax(prev, val_of(k));
+            if (k == kv) sfirst = fmin(sfirst, (double)si);
           });
-          prev = block_reduce<OpMax, BLOCK>(prev, red);
+          {  // the largest draw below v and the first (lowest index) of the draws equal to v, in one exchange
+            double none[1] = {0.0}, m2[2] = {prev, -sfirst};
+            block_reduce_mix<0, 2, BLOCK>(none, m2, mix);
+            prev = m2[0];
+            sfirst = -m2[1];
+          }
           // Equal draws: the reference walks the SORTED draws one by one (542-554), so inside a group of equal draws only
           // its first member interpolates from the value below -- with its own weight -- and a target crossed at any later
           // member has x1 == x_sorted[wi] and returns v exactly.  (Collapsing the group into one draw of the combined weight
           // gave 4.36 where the reference gives 5.0 on count data.)  The reference's order inside the group is that of an
           // unstable argsort; here it is draw order: the first member is the tied draw with the lowest index.
-          double sfirst = 1e300;
-          each_s([&](const uint64_t k, const double, const int si) {
-            if (k == kv) sfirst = fmin(sfirst, (double)si);
-          });
-          sfirst = block_reduce<OpMin, BLOCK>(sfirst, red);
           double wfirst = 0.0;
           each_s([&](const uint64_t, const double w, const int si) {
             if ((double)si == sfirst) wfirst = w;
@@ -905,6 +978,9 @@ __global__ __launch_bounds__(BLOCK) void e_loo_quantile_kernel(EQuantParams P) {
       }
       if (tid == 0) P.out[r * P.n_probs + ip] = res;
       __syncthreads();
+    }
+    if constexpr (FAST) {
+      if (declined && tid == 0) P.slow_list[atomicAdd(P.slow_count, 1ull)] = (unsigned)r;
     }
   }
 }

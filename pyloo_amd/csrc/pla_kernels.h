@@ -99,7 +99,8 @@ hipError_t launch_e_loo(const void* x, const void* lw, const void* lr, int dtype
                         hipStream_t stream);
 // weighted quantiles of e_loo (e_loo.py:468-515, 534-554): out[n_obs][n_probs]; probs is a DEVICE pointer
 hipError_t launch_e_loo_quantiles(const void* x, const void* lw, int dtype, int64_t n_obs, int n_draws, int64_t stride_obs,
-                                  int64_t stride_draw, const double* probs, int n_probs, double* out, hipStream_t stream);
+                                  int64_t stride_draw, const double* probs, int n_probs, double* out, unsigned* slow_list,
+                                  unsigned long long* slow_count, hipStream_t stream);  // slow_list: [n_obs] scratch (may be null)
 // Observations-fastest PSIS-LOO without a transposing pass (pla_col.h): lane-per-observation sweep + per-observation
 // selection + the fit kernel of the split pass.  `p`: in = first observation of the block, stride_obs = 1, stride_draw = ld,
 // ws_y / ws_s / slow_list / counters / l1_table set as for the split pass.  col_ws: col_workspace_bytes(n_obs) of device memory.

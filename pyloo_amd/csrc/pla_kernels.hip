@@ -345,7 +345,7 @@ static hipError_t launch_fit_stream(const RowsParams& p, const FastParams& f, in
   q.fitted = sync + 48 + nchunks;
   // looks are 1-2 us apart (s_sleep 32 + one load from memory): a few seconds of them, then the chunk is left to the plain fit
   // kernel that follows -- nothing then depends on the two kernels having been run side by side
-  static const int patience = debug_flag("PLA_STREAM_PATIENCE");
+  const int patience = debug_flag("PLA_STREAM_PATIENCE");  // (read per call: a test lets the fit kernel give up at once)
   q.patience = patience > 0 ? (unsigned)patience : 2000000u;
   static const int fg_forced = debug_flag("PLA_FIT_GRID");
   int64_t g = nchunks < 256 ? nchunks : 256;
@@ -828,14 +828,27 @@ hipError_t launch_e_loo(const void* x, const void* lw, const void* lr, int dtype
 }
 
 hipError_t launch_e_loo_quantiles(const void* x, const void* lw, int dtype, int64_t n_obs, int n_draws, int64_t stride_obs,
-                                  int64_t stride_draw, const double* probs, int n_probs, double* out, hipStream_t stream) {
+                                  int64_t stride_draw, const double* probs, int n_probs, double* out, unsigned* slow_list,
+                                  unsigned long long* slow_count, hipStream_t stream) {
   if (n_obs <= 0 || n_probs <= 0) return hipSuccess;
   EQuantParams p{x, lw, n_obs, n_draws, stride_obs, stride_draw, probs, n_probs, out};
   const int64_t grid = n_obs < 16384 ? n_obs : 16384;
-  // (512 threads per observation: eight draws per thread in registers instead of sixteen -- 104 registers, four waves per SIMD,
-  // where 256 threads needed 260 and ran one workgroup per CU)
-  if (dtype == PLA_F64) hipLaunchKernelGGL((e_loo_quantile_kernel<double, 512>), dim3((unsigned)grid), dim3(512), 0, stream, p);
-  else hipLaunchKernelGGL((e_loo_quantile_kernel<float, 512>), dim3((unsigned)grid), dim3(512), 0, stream, p);
+  // 512 threads per observation, eight draws per thread in registers.  Rows of up to 4096 draws go through the FAST variant
+  // (histogram path only: 128 registers, two workgroups per CU) and the few it lists through the general one behind it.
+  const bool two = slow_list && slow_count && n_draws <= 4096 && n_obs <= 0xffffffffll;
+  if (two) {
+    hipError_t e = hipMemsetAsync(slow_count, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    p.slow_list = slow_list;
+    p.slow_count = slow_count;
+    if (dtype == PLA_F64) hipLaunchKernelGGL((e_loo_quantile_kernel<double, 512, true>), dim3((unsigned)grid), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((e_loo_quantile_kernel<float, 512, true>), dim3((unsigned)grid), dim3(512), 0, stream, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  const int64_t g2 = two ? (n_obs < 2048 ? n_obs : 2048) : grid;
+  if (dtype == PLA_F64) hipLaunchKernelGGL((e_loo_quantile_kernel<double, 512>), dim3((unsigned)g2), dim3(512), 0, stream, p);
+  else hipLaunchKernelGGL((e_loo_quantile_kernel<float, 512>), dim3((unsigned)g2), dim3(512), 0, stream, p);
   return hipGetLastError();
 }
 
