@@ -510,12 +510,18 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
   static const int64_t kColBlock = [] {  // observations per launch: 8 KB of candidate lists each (PLA_COL_BLOCK: A/B runs)
     const char* e = getenv("PLA_COL_BLOCK");
     const int64_t v = e ? atoll(e) : 0;
-    return v >= 256 ? v : (int64_t)262144;
+    // (at most 262 144: the lists of one launch are addressed with 32-bit byte offsets, 8 KB per observation)
+    return v >= 256 ? (v <= 262144 ? v : (int64_t)262144) : (int64_t)262144;
   }();
   int col_kq = 0;
   static const bool force_transpose = getenv("PLA_INGEST_TRANSPOSE") && atoi(getenv("PLA_INGEST_TRANSPOSE")) != 0;
   constexpr int64_t kDevBlock = (int64_t)1 << 20;  // rows per launch of a device-resident matrix (bounds the hand-over buffer)
-  const bool use_col = ingest && method == PLA_PSIS && !force_transpose && pla::col_supported((int)n_draws, (int)tail_count, &col_kq);
+  // (the column sweep addresses the draws of a batch with 32-bit byte offsets from the batch's first draw -- sixteen draws at
+  // most -- plus the lane's observation inside the block: matrices whose draws lie further apart than that allows take the
+  // transposing path instead of reading zeros past a descriptor's range)
+  const bool col_offsets_fit = (double)stride_draw * (double)esz * 16.0 + (double)kColBlock * (double)esz < 2147483648.0;
+  const bool use_col = ingest && method == PLA_PSIS && !force_transpose && col_offsets_fit &&
+                       pla::col_supported((int)n_draws, (int)tail_count, &col_kq);
   // Streamed split pass (device-resident, draws-fastest matrices): the fit kernel runs BESIDE the wave kernel, in the registers
   // and LDS that kernel leaves free on a CU, and takes the chunks of observations as they are finished (pla_kernels.hip,
   // launch_wave).  PLA_PIPE=0: the two kernels back to back on the caller's stream (round 2's arrangement; A/B runs).
