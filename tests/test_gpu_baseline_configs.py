@@ -85,20 +85,28 @@ def test_streamed_pass_equals_the_kernels_back_to_back(eng, n_obs, monkeypatch):
     eng.fill_synthetic(t, seed=0x5EED0002, k_lo=0.05, k_hi=0.9)
     t[min(7, n_obs - 1), 11] = float("inf")
     t[n_obs // 2, 5] = -float("inf")
+    # a second matrix, visited in turn with the first: the hand-over buffer is reused by every pass, so a stale read would
+    # deliver the OTHER matrix's tail -- which the same matrix twice in a row could never show
+    other = torch.empty_like(t)
+    eng.fill_synthetic(other, seed=0x5EED0009, k_lo=0.05, k_hi=0.5)
     M = orc.tail_count(S, 1.0)
 
-    def run(pipe):
+    def run(pipe, m=None):
         monkeypatch.setenv("PLA_PIPE", pipe)
-        r = eng.psis_loo(t, M, "psis", 1.0, 0.7)
+        r = eng.psis_loo(t if m is None else m, M, "psis", 1.0, 0.7)
         torch.cuda.synchronize()
         return {k: r[k].clone() for k in ("diag", "loo_i", "lppd_i", "agg")}
 
-    ref = run("0")
+    ref, ref_other = run("0"), run("0", other)
+    assert not torch.equal(ref["loo_i"], ref_other["loo_i"])
     for _ in range(4):
+        got_other = run("1", other)
         got = run("1")
         for k in ref:
             same = (ref[k] == got[k]) | (torch.isnan(ref[k]) & torch.isnan(got[k]))
             assert bool(same.all()), (k, int((~same).sum()))
+            assert torch.equal(ref_other[k], got_other[k]), ("other matrix", k)
+    del other
     # the fit kernel gives up waiting after ONE look at a chunk's flag (what a profiler that serialises the two kernels the
     # wrong way round would cause, after seconds): whatever it left is fitted by the plain fit kernel behind it -- same bits
     monkeypatch.setenv("PLA_STREAM_PATIENCE", "1")
