@@ -80,7 +80,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
   const unsigned lim8 = cand0 + 8u * kCand;
   unsigned next8 = cand0, base8 = cand0;
   const char* tabc = reinterpret_cast<const char*>(tb.tab);
-  bool thr_miss = false;  // lost to the threshold alone (as opposed to non-finite draws or the range)
   unsigned c_first = 0;   // draws of the first chunk above the threshold
 
   wave_sync();  // previous row is done with the LDS scratch
@@ -120,10 +119,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
         }
         if (mc - mnc < kWaveMaxRange) {
           // (the exact counts look at this first chunk only: the rest of the row has not been read yet)
-          if (!wave_threshold_check<T, VEC, LW>(v, F, mnc, mc, hi)) {
-            slow = true;
-            thr_miss = true;
-          }
+          if (!wave_threshold_check<T, VEC, LW>(v, F, mnc, mc, hi)) slow = true;
         }
       } else {
         // second attempt: the row's maximum is known (the shift is final from the start) and so is the threshold
@@ -131,10 +127,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
         hi = t_second;
       }
       t1p = hi - mp;
-      if (!(t1p < 0.0)) {
-        slow = true;
-        thr_miss = true;
-      }
+      if (!(t1p < 0.0)) slow = true;
     }
     if (ch == 1) c_first = (next8 - cand0) >> 3;
     // a non-finite maximum (inf / NaN draws) or a range that may overflow the sums: general kernel.
@@ -264,7 +257,6 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
       }
     }
   }
-  (void)thr_miss;
   if (!slow) {
     for (unsigned c = lane; c < ncand; c += kWave) sm.cand[c] = LW ? sm.cand[c] - m : (-sm.cand[c]) - m;  // psis.py:134, one rounding
     s1 *= exp_tab(-delta, tb.tab);  // e^x = e^x' e^-(m - m');  s2 is rescaled in log space (lppd_shift)

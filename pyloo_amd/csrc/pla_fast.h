@@ -61,8 +61,7 @@ struct FastParams {
   // Streamed split pass (pla_fit.h, fit_rows_stream_kernel): the fit kernel runs BESIDE this kernel and takes the chunks of
   // kQueueChunk rows as they are finished: done[c] is set (agent scope) once every hand-over store of chunk c has drained.
   unsigned* done = nullptr;
-  int retry_k = 0;                // long rows, second attempt (pla_chunked.h): order statistic of the 64 x chunks per-lane chunk maxima (0: none)
-  int retry_target = 0;           // ... and the number of draws the second attempt wants above its threshold
+  int retry_target = 0;           // long rows that come round again (pla_chunked.h, ChunkRetry): the number of draws a later attempt wants above its threshold (0: rows do not return)
   int prio = 0;                   // s_setprio of the wave kernel's waves (streamed pass: the fit kernel beside it takes what is left)
 };
 #ifndef PLA_QUEUE_CHUNK

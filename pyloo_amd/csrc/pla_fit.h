@@ -580,15 +580,10 @@ __global__ __launch_bounds__(kWave * W, PLA_FIT_MIN_WAVES) void fit_rows_kernel(
 // The same fit for the streamed pass (pla_kernels.hip, launch_wave): it runs BESIDE the wave kernel, in what two workgroups of
 // that kernel leave free on a CU -- 512 - 2 x 192 = 128 vector registers per SIMD and 160 KB - 2 x 58 KB of LDS -- so it is
 // compiled for at most 128 registers (four waves per workgroup, 39.5 KB of LDS: one workgroup per CU beside the wave kernel's
-// two).  fit_rows_stream_kernel takes the chunks as the wave kernel finishes them; fit_rows_slim_kernel walks its groups in a
-// fixed order (experiments).
+// two).  fit_rows_stream_kernel takes the chunks as the wave kernel finishes them.
 #ifndef PLA_FIT_SLIM_WAVES
 #define PLA_FIT_SLIM_WAVES 4  // waves per SIMD the register budget is derived from: 4 -> 128 registers (5 -> 96: spills)
 #endif
-template <int NQ, int G = 3, int W = 2>
-__global__ __launch_bounds__(kWave * W, PLA_FIT_SLIM_WAVES) void fit_rows_slim_kernel(FitParams Q) {
-  fit_rows_body<NQ, G, W, true>(Q);
-}
 template <int NQ, int G = 3>
 __global__ __launch_bounds__(kWave * 4, PLA_FIT_SLIM_WAVES) void fit_rows_stream_kernel(FitParams Q) {
   fit_rows_body<NQ, G, 4, true, true>(Q);

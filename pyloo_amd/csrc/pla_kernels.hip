@@ -295,8 +295,6 @@ static int debug_flag(const char* name) {
 // short-lived waves pay that start-up again and again), at most 8 rounds (many rounds even out clock and memory-channel luck)
 static int64_t wave_grid(int64_t n_obs, int waves) {
   const int64_t need = (n_obs + waves - 1) / waves;
-  static const int forced = debug_flag("PLA_WAVE_GRID");  // experiments
-  if (forced > 0) return forced < need ? forced : need;
   if (need <= 512) return need < 1 ? 1 : need;
   int64_t grid = 512;
   while (grid < 4096 && n_obs / (2 * grid * waves) >= 24) grid *= 2;
@@ -461,14 +459,7 @@ static hipError_t launch_wave(const RowsParams& p, int gsz, int kq, int bits, co
         e = launch_fit(p, f, mestM, stream, sync + 48 + nchunks, sync + 32);
         if (e != hipSuccess) return e;
       } else {
-        static const int queue_too = debug_flag("PLA_QUEUE");  // A/B: dynamic row queue without the streamed fit
-        int64_t g1 = grid;
-        if (queue_too && pipe && pipe->sync) {
-          e = hipMemsetAsync(pipe->sync, 0, 64, stream);
-          if (e != hipSuccess) return e;
-          f.queue = pipe->sync;
-          g1 = g1 < 512 ? g1 : 512;
-        }
+        const int64_t g1 = grid;
         note_kernels("wave_loo_kernel<%s, SPLIT> (statistics, sweep, tail selection) + fit_rows_kernel<%d> (GPD fit, smoothing, "
                      "outputs) + slow_rows_kernel (declined rows), back to back", tname<T>(), p.ws_stride / 64);
         hipLaunchKernelGGL((wave_loo_kernel<T, VEC, false, CapsSmall, true>), dim3((unsigned)g1), dim3(kWave * kWavesPerBlock), 0,
@@ -509,14 +500,11 @@ static hipError_t launch_chunked(const RowsParams& p, int gsz, int kq, int bits,
   f.sample_bits = bits;
   f.cr_lo = chk.cr_lo; f.cr_hi = chk.cr_hi;
   {
-    // second attempt of a row whose first-chunk threshold missed: the k-th smallest of its 64 x chunks per-lane chunk maxima
-    // (groups of 64 draws: a draw lies below it with probability F, F^64 = k / (64 chunks)) with ~PLA_CAND_MULT (M + 1) draws above
+    // rows whose first-chunk threshold misses come round again (pla_chunked.h, ChunkRetry): what a later attempt aims at is the
+    // middle of what the list accepts.  PLA_NO_RETRY=1: such rows go to the general kernel as in round 2 (A/B runs).
     static const int no_retry = debug_flag("PLA_NO_RETRY");
     const int nch = (p.n_draws + kChunkDraws - 1) / kChunkDraws;
-    const double Fq = 1.0 - PLA_CAND_MULT * (p.tail_count + 1) / (double)p.n_draws;
-    const int k = (int)std::lround(64.0 * nch * std::pow(Fq, 64.0));
-    f.retry_k = (!no_retry && nch > 1 && k >= 6 && k <= 32 * nch) ? k : 0;
-    f.retry_target = no_retry ? 0 : (int)(0.5 * ((p.tail_count + 1) + (double)CAP::kCand));  // the middle of what the list accepts
+    f.retry_target = (no_retry || nch < 1) ? 0 : (int)(0.5 * ((p.tail_count + 1) + (double)CAP::kCand));
   }
   constexpr int W = CAP::kWaves;  // waves per workgroup; two workgroups per CU (LDS)
   int64_t grid = (p.n_obs + W - 1) / W;

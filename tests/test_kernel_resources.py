@@ -42,7 +42,13 @@ KERNELS = {
     "col_sweep_kernelIf": 81920,
     "col_select_kernel": 81920,
     "waic_col_kernelId": 81920,
-    "e_loo_quantile_kernelIdLi256": 81920,
+    "e_loo_quantile_kernelIdLi512ELb0": 81920,      # general variant (radix descent in its code)
+}
+# kernels that are allowed a few dwords of scratch, with the reason
+SCRATCH_OK = {
+    # FAST variant of the quantile kernel: compiled for 128 registers so that two 512-thread workgroups fit a CU (one
+    # workgroup's barriers are then the other's issue slots: 13.8 -> 11.9 ms); 34 dwords of invariants live in scratch
+    "e_loo_quantile_kernelIdLi512ELb1": 192,
 }
 
 
@@ -60,6 +66,9 @@ def test_row_kernels_do_not_spill(tmp_path):
         assert not any(k.startswith("scratch_") for k in total), (name, dict(total))
         assert res.get("NumVgprs", 0) <= 256 and res.get("Occupancy", 0) >= 1, (name, res)
         assert res.get("LDSByteSize", 0) <= lds_limit, (name, res)  # two workgroups per CU (160 KB LDS)
+    for pat, limit in SCRATCH_OK.items():
+        name, total, _, res = isa_stats.kernel_stats(lines, pat)
+        assert res.get("ScratchSize", 0) <= limit and res.get("NumVgprs", 0) <= 128, (name, res)
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
