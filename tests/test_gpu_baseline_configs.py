@@ -208,6 +208,39 @@ print("rccl ok", a[1])
     assert proc.returncode == 0 and "rccl ok" in proc.stdout, proc.stdout[-1000:] + proc.stderr[-3000:]
 
 
+def test_chain_generator_and_kernel_record(eng):
+    """`pla_fill_synthetic_chains` (bench.py --rows chain_ar1): chain-major AR(1) rows -- lag-1 autocorrelation of the Gaussian
+    scores near rho inside a chain, none across the chain boundary, per-chain offsets present -- stay on the fast path, equal
+    the oracle, and `pla_engine_last_kernels` names what ran."""
+    import torch
+    from scipy.special import ndtri
+
+    n, S, chains, rho = 2000, 4000, 4, 0.9
+    t = torch.empty((n, S), dtype=torch.float64, device="cuda")
+    eng.fill_synthetic_chains(t, seed=11, chains=chains, rho=rho, offset_sd=0.0, k_lo=0.3, k_hi=0.3)
+    x = t.cpu().numpy()
+    per = S // chains
+    # undo the marginal map: ll = -k E + c with E = -log(1 - Phi(z)), k = 0.3, c = -1 - (i mod 7) / 4
+    c = -1.0 - (np.arange(n) % 7) * 0.25
+    E = -(x - c[:, None]) / 0.3
+    z = ndtri(np.clip(1.0 - np.exp(-E), 1e-300, 1 - 1e-16))
+    inside = np.mean(z[:, 1:per] * z[:, :per - 1])
+    across = np.mean(z[:, per] * z[:, per - 1])
+    assert abs(inside - rho) < 0.02 and abs(across) < 0.08, (inside, across)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01
+    eng.fill_synthetic_chains(t, seed=12, chains=chains, rho=rho, offset_sd=0.1)
+    res = eng.psis_loo(t, orc.tail_count(S, 1.0), "psis", 1.0, 0.7)
+    assert res["agg"][7].item() == 0  # nothing for the general kernel
+    idx = np.arange(0, n, 50)
+    ref = orc.loo_arrays(t[torch.from_numpy(idx).cuda()].cpu().numpy(), 1.0)
+    close(res["diag"].cpu().numpy()[idx], ref["khat"], what="khat")
+    close(res["loo_i"].cpu().numpy()[idx], ref["loo_i"], what="loo_i")
+    text = eng.last_kernels()
+    assert "wave_loo_kernel<double" in text and "fit_rows_stream_kernel" in text, text
+    lw, _ = eng.importance_weights(-t[:64], 190, "psis")
+    assert "weights" in eng.last_kernels()
+
+
 def test_aggregate_pack_and_merge_kernels(eng):
     """`pla_aggregate_pack` / `pla_aggregate_merge` (one kernel each around the single all-reduce of a multi-GPU step): three
     ranks' tables packed on one device and summed as the all-reduce would, merged, against the NumPy Chan merge."""
