@@ -59,6 +59,15 @@ def host_cpu_model():
     return platform.processor() or platform.machine()
 
 
+def rccl_version(torch):
+    """Version of the collective library torch.distributed's "nccl" backend is built on (RCCL on ROCm), or None."""
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:  # (a record field: never worth failing the run for)
+        return None
+
+
 def launch_ranks(n):
     """Start ``n`` ranks of this script through torch.distributed.run (children of a parent that never initialises
     the GPU), pass their output through and return the launcher's exit code."""
@@ -216,7 +225,10 @@ def main():
     if world > 1:
         mine = {"rank": rank, "device": dev_index, "name": torch.cuda.get_device_name(dev_index), "kernel_ms": kernel_ms}
         per_rank = [None] * world
-        dist.all_gather_object(per_rank, mine)
+        try:
+            dist.all_gather_object(per_rank, mine)
+        except Exception:  # (record fields only: the throughput line does not depend on them)
+            per_rank = None
 
     if rank != 0:
         if world > 1:
@@ -232,7 +244,7 @@ def main():
         "n_gpus": world,
         "ranks": world,
         "backend": (backend if world > 1 else None),
-        "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 and backend == "nccl" else None),
+        "rccl_version": rccl_version(torch) if world > 1 and backend == "nccl" else None,
         "devices_seen": ([r["device"] for r in per_rank] if per_rank else [dev_index]),
         "kernel_ms_per_rank": ({"min": min(r["kernel_ms"] for r in per_rank), "max": max(r["kernel_ms"] for r in per_rank)} if per_rank else None),
         "steps": args.steps,
