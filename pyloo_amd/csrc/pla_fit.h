@@ -84,8 +84,9 @@ template <bool STREAM>
 __device__ __forceinline__ double2 ws_load2(const double* base, const int64_t elem) {
   if constexpr (STREAM) {
     typedef int v4i __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, 0x7fffffff, 0x00020000);
-    const v4i t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(elem * 8), 0, 16);  // aux 16 = sc1
+    // (offsets are unsigned 32-bit: a block of 2^20 observations at the widest hand-over stride, 256 doubles, ends at 2^31 bytes)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, (int)0xfffffff0u, 0x00020000);
+    const v4i t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(unsigned)((uint64_t)elem * 8u), 0, 16);  // aux 16 = sc1
     return make_double2(__hiloint2double(t[1], t[0]), __hiloint2double(t[3], t[2]));
   } else {
     return *reinterpret_cast<const double2*>(base + elem);

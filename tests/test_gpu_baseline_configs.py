@@ -125,6 +125,34 @@ def test_streamed_pass_equals_the_kernels_back_to_back(eng, n_obs, monkeypatch):
     torch.cuda.empty_cache()
 
 
+def test_streamed_pass_full_block_at_the_widest_hand_over(eng, monkeypatch):
+    """A full block of 2^20 observations at the widest hand-over stride of the streamed pass (tail counts 193..250 -> 256
+    doubles per observation: reff = 0.7 at S = 4000): the block's hand-over ends at 2^31 bytes, the edge of what the fit
+    kernel's 32-bit buffer offsets reach.  Every row of the block (and the rows of the short block behind it) against the two
+    kernels back to back."""
+    import torch
+
+    S, n = 4000, (1 << 20) + 77
+    M = orc.tail_count(S, 0.7)
+    assert 192 < M <= 250
+    t = torch.empty((n, S), dtype=torch.float64, device="cuda")
+    eng.fill_synthetic(t, seed=0x5EED000A)
+    out = {}
+    for pipe in ("0", "1"):
+        monkeypatch.setenv("PLA_PIPE", pipe)
+        r = eng.psis_loo(t, M, "psis", 1.0, 0.7)
+        torch.cuda.synchronize()
+        out[pipe] = {k: r[k].clone() for k in ("diag", "loo_i", "lppd_i", "agg")}
+    for k in out["0"]:
+        assert torch.equal(out["0"][k], out["1"][k]), k
+    idx = np.array([0, 1, (1 << 20) - 2, (1 << 20) - 1, 1 << 20, n - 1])
+    ref = orc.loo_arrays(t[torch.from_numpy(idx).cuda()].cpu().numpy(), 0.7)
+    close(out["1"]["diag"].cpu().numpy()[idx], ref["khat"], what="khat")
+    close(out["1"]["loo_i"].cpu().numpy()[idx], ref["loo_i"], what="loo_i")
+    del t
+    torch.cuda.empty_cache()
+
+
 def test_c5_shard(eng):
     """One GPU's shard of C5: S=20 000 x N=125 000 f32 (10 GB), seed 0x5EED0005, rows with i mod 10 in {0, 3, 6} drawn
     with k in [1, 1.3): ~30 % of the observations end above khat = 0.7.  500 rows against the oracle on the upcast data."""
