@@ -522,6 +522,8 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
   const bool col_offsets_fit = (double)stride_draw * (double)esz * 16.0 + (double)kColBlock * (double)esz < 2147483648.0;
   const bool use_col = ingest && method == PLA_PSIS && !force_transpose && col_offsets_fit &&
                        pla::col_supported((int)n_draws, (int)tail_count, &col_kq);
+  int tile_ks = 0;
+  const bool use_tile = use_col && pla::tile_supported(dtype, (int)n_draws, (int)tail_count, stride_draw, &tile_ks);
   // Streamed split pass (device-resident, draws-fastest matrices): the fit kernel runs BESIDE the wave kernel, in the registers
   // and LDS that kernel leaves free on a CU, and takes the chunks of observations as they are finished (pla_kernels.hip,
   // launch_wave).  PLA_PIPE=0: the two kernels back to back on the caller's stream (round 2's arrangement; A/B runs).
@@ -546,7 +548,8 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
       // hand-over buffers of the split pass (one-chunk wave kernel -> fit kernel, pla_fit.h): sized for the
       // rows one launch processes (all of them on the device path, one staging chunk on the host path)
       if ((tail_count <= 250 && n_draws >= 256 && n_draws <= 4096) || (tail_count <= 448 && n_draws >= 256)) {  // (one-chunk / chunked wave kernels)
-        const int64_t chunk_rows = use_col ? (n_obs < kColBlock ? n_obs : kColBlock) : staged_chunk_rows(mem_space, ingest, n_obs, n_draws, esz);
+        const int64_t col_rows = use_tile ? kDevBlock : kColBlock;
+        const int64_t chunk_rows = use_col ? (n_obs < col_rows ? n_obs : col_rows) : staged_chunk_rows(mem_space, ingest, n_obs, n_draws, esz);
         // (device-resident matrices run in blocks of kDevBlock rows, so the buffer is bounded: 1.7 GB at M = 190 however
         // many observations there are)
         int64_t rows = (mem_space == PLA_DEVICE && !ingest) ? (n_obs < kDevBlock ? n_obs : kDevBlock) : chunk_rows;
@@ -597,6 +600,27 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
       if (!dd) dd = eng->d_pw;
       if (!dl) dl = eng->d_pw + n_obs;
       if (!dp) dp = eng->d_pw + 2 * n_obs;
+    }
+    if (use_tile && p.ws_y) {
+      // observations-fastest input, read in place: a workgroup per 16 observations, candidate lists in LDS (pla_tile.h)
+      p.stride_obs = 1;
+      p.stride_draw = stride_draw;
+      for (int64_t r0 = 0; r0 < n_obs; r0 += kDevBlock) {
+        const int64_t nr = (n_obs - r0 < kDevBlock) ? (n_obs - r0) : kDevBlock;
+        TimedLaunch t(eng, s);
+        p.in = (const char*)ll + (size_t)r0 * esz;
+        p.n_obs = nr;
+        p.diag = dd ? dd + r0 : nullptr;
+        p.loo_i = dl ? dl + r0 : nullptr;
+        p.lppd_i = dp ? dp + r0 : nullptr;
+        PLA_HIP(pla::launch_tile(p, dtype, tile_ks, s));
+        eng->last_kernels = "tile_loo_kernel (a workgroup per 16 observations, matrix read in place) + fit_rows_kernel + slow_rows_kernel";
+      }
+      if (agg) {
+        pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, agg, eng->counters + 1};
+        PLA_HIP(pla::launch_reduce(rp, eng->d_red, s));
+      }
+      return PLA_OK;
     }
     if (use_col && p.ws_y) {
       // observations-fastest input, read in place: one lane per observation (pla_col.h), block by block of observations

@@ -25,6 +25,7 @@
 #include "pla_fit.h"
 #include "pla_eloo.h"
 #include "pla_col.h"
+#include "pla_tile.h"
 
 namespace pla {
 
@@ -776,6 +777,63 @@ hipError_t launch_col(const RowsParams& p, int dtype, int kq, void* col_ws, hipS
     hipLaunchKernelGGL((slow_rows_kernel<double, BLOCK, false>), dim3((unsigned)g3), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap), stream, p);
   else
     hipLaunchKernelGGL((slow_rows_kernel<float, BLOCK, false>), dim3((unsigned)g3), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap), stream, p);
+  return hipGetLastError();
+}
+
+// ---- observations-fastest LOO, a workgroup per 16 observations (pla_tile.h) -------------------------------------------------
+// The threshold is the sample's ks-th largest value: ks / 512 of the row is expected at or above it, T = ks S / 512 draws, with a
+// standard deviation of sqrt(S^2 p (1 - p) / 512 + S p (1 - p)), p = T / S (the sample's quantile, then the row's count given the
+// quantile).  T sits halfway between the M + 1 the selection needs and the list's capacity; shapes where that leaves less than
+// 3.0 standard deviations on either side stay with the lane-per-observation kernels (pla_col.h).
+bool tile_supported(int dtype, int n_draws, int tail_count, int64_t ld, int* ks) {
+  static const int off = debug_flag("PLA_NO_TILE");
+  if (off || dtype != PLA_F64) return false;
+  if (n_draws < kTileSample || tail_count > CapsSmall::kMaxTail || tail_count < 1) return false;
+  if ((double)ld * 8.0 * 4.0 >= 4294967296.0) return false;  // the lane's draw inside a step rides in a 32-bit offset
+  const double target = 0.5 * (tail_count + 1 + kTileCap);
+  int k = (int)std::lround(target * kTileSample / n_draws);
+  if (k < 2) return false;
+  if (k > kTileSample - 1) k = kTileSample - 1;   // (short rows: nearly every draw is a candidate, and fits)
+  const double p = (double)k / kTileSample, T = p * n_draws;
+  const double sd = std::sqrt((double)n_draws * n_draws * p * (1 - p) / kTileSample + n_draws * p * (1 - p));
+  if (n_draws > kTileCap && (T - (tail_count + 1) < 3.0 * sd || kTileCap - T < 3.0 * sd)) return false;
+  if (n_draws <= kTileCap && T - (tail_count + 1) < 3.0 * sd) return false;
+  *ks = k;
+  return true;
+}
+
+hipError_t launch_tile(const RowsParams& p, int dtype, int ks, hipStream_t stream) {
+  if (p.n_obs <= 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return e;
+  int root_ = (int)std::sqrt((double)p.tail_count);
+  while (root_ * root_ > p.tail_count) --root_;
+  while ((root_ + 1) * (root_ + 1) <= p.tail_count) ++root_;
+  const int mestM = 30 + root_;
+  TileParams c{p.in, p.n_obs, p.n_draws, p.stride_draw, ks};
+  FastParams f{0, 0, p.slow_list, p.counters, 0, p.l1_table, std::log((double)p.n_draws), p.l1_table + p.tail_count, mestM};
+  f.ws_y = p.ws_y;
+  f.ws_s = p.ws_s;
+  f.ws_stride = p.ws_stride;
+  f.ws_sstride = p.ws_sstride;
+  static const bool attr_set = [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_loo_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)sizeof(TileSmem<double>)) == hipSuccess;
+  }();
+  if (!attr_set) return hipErrorInvalidValue;
+  const int64_t ngroups = (p.n_obs + 15) / 16;
+  static const int grid_env = debug_flag("PLA_TILE_GRID");
+  const int64_t cap = grid_env > 0 ? grid_env : 256;  // one workgroup per CU (144 KB of LDS each)
+  const unsigned g1 = (unsigned)(ngroups < cap ? ngroups : cap);
+  hipLaunchKernelGGL(tile_loo_kernel<double>, dim3(g1), dim3(kTileThreads), sizeof(TileSmem<double>), stream, c, f, p.tail_count);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = launch_fit(p, f, mestM, stream);
+  if (e != hipSuccess) return e;
+  // rows the tile kernel declined: the general kernel walks them with the matrix's strides
+  constexpr int BLOCK = 256;
+  int64_t g3 = p.n_obs < 1024 ? p.n_obs : 1024;
+  hipLaunchKernelGGL((slow_rows_kernel<double, BLOCK, false>), dim3((unsigned)g3), dim3(BLOCK), smem_bytes(BLOCK, p.tail_cap), stream, p);
   return hipGetLastError();
 }
 

@@ -776,3 +776,40 @@ def test_column_kernels_on_observation_fastest_matrices(eng):
     close(a["diag"].cpu().numpy()[idx], ref["khat"], what="khat")
     close(a["loo_i"].cpu().numpy()[idx], ref["loo_i"], what="loo_i")
     close(a["lppd_i"].cpu().numpy()[idx], ref["lppd_i"], what="lppd_i")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,S,reff", [(300_011, 4000, 0.7), (100_003, 1000, 1.0), (50_001, 777, 1.0), (20_000, 4096, 0.7)])
+def test_tile_kernel_on_observation_fastest_f64_matrices(eng, N, S, reff):
+    """pla_tile.h: a workgroup per 16 observations on an f64 (S, N) buffer -- a ragged last group, row lengths with steps behind
+    the last whole batch and draws behind the last whole step, heavy-tailed rows, rows with non-finite draws and a constant row
+    (general kernel through the strided view), against the draws-fastest pass and the oracle."""
+    import torch
+
+    t = torch.empty((N, S), dtype=torch.float64, device="cuda")
+    eng.fill_synthetic(t, seed=1234 + S, k_lo=0.05, k_hi=1.1)
+    t[7, 100] = float("nan")
+    t[N // 3, 3] = float("inf")
+    t[N // 2] = -3.0  # a constant row: every weight equal, k = inf (psis.py:142-144 through ties at the cutoff)
+    t[N - 1, S - 1] = -40.0  # the very last element of the matrix: by far the largest raw value of its row
+    M = orc.tail_count(S, reff)
+    view = t.T.contiguous().T  # (N, S) view of an (S, N) buffer: observations fastest
+    assert view.stride(0) == 1
+    a = eng.psis_loo(view, M, "psis", 1.0, 0.7)
+    assert "tile_loo_kernel" in eng.last_kernels()
+    b = eng.psis_loo(t, M, "psis", 1.0, 0.7)
+    torch.cuda.synchronize()
+    for key in ("diag", "loo_i", "lppd_i"):
+        x, y = a[key].cpu().numpy(), b[key].cpu().numpy()
+        assert np.array_equal(np.isnan(x), np.isnan(y)) and np.array_equal(np.isinf(x), np.isinf(y)), key
+        ok = np.isfinite(y)
+        np.testing.assert_allclose(x[ok], y[ok], rtol=1e-10, atol=1e-11, err_msg=key)
+    assert a["agg"][7].item() <= 0.01 * N
+    a2 = eng.psis_loo(view, M, "psis", 1.0, 0.7)  # (lists are appended to in whatever order the waves arrive: the results may not depend on it)
+    for key in ("diag", "loo_i", "lppd_i", "agg"):
+        assert torch.equal(a[key], a2[key]) or np.array_equal(a[key].cpu().numpy(), a2[key].cpu().numpy(), equal_nan=True), key
+    idx = np.r_[0:40, 7, N // 3, N // 2 - 20:N // 2 + 20, N - 30:N]
+    ref = orc.loo_arrays(t[torch.from_numpy(idx).cuda()].cpu().numpy(), reff)
+    close(a["diag"].cpu().numpy()[idx], ref["khat"], what="khat")
+    close(a["loo_i"].cpu().numpy()[idx], ref["loo_i"], what="loo_i")
+    close(a["lppd_i"].cpu().numpy()[idx], ref["lppd_i"], what="lppd_i")
