@@ -14,7 +14,7 @@
 //
 //   per group of 16 observations:
 //   A  sample: 16 draws per lane, spread over the row (every chain of a chain-major stack contributes), as f32 keys to LDS
-//   B  threshold: the sample's ks-th largest value, by bisection on exact counts (one wave per observation, ballots)
+//   B  threshold: the sample's ks-th largest value, by two levels of a 64-bin histogram (one wave per observation)
 //   C  sweep: every draw once -- max / min, the two sums of e^x', e^-x' about the provisional shift (the sample's maximum), and
 //      the draws at or above the threshold appended to the observation's list
 //   D  selection on the list with the true shift (psis.py:134: x = raw - max raw in one rounding), hand-over to the fit kernel
@@ -24,20 +24,25 @@
 
 namespace pla {
 
-#ifndef PLA_TILE_U
-#define PLA_TILE_U 12      // steps per batch; two batches in flight per lane
-#endif
 #ifndef PLA_TILE_CAP
 #define PLA_TILE_CAP 640   // candidate list capacity per observation
 #endif
-#ifndef PLA_TILE_ILP
-#define PLA_TILE_ILP 4     // draws the scheduler may interleave
+#ifndef PLA_TILE_RING
+#define PLA_TILE_RING 24   // steps in flight per lane
+#endif
+#ifndef PLA_TILE_PF
+#define PLA_TILE_PF 4      // depth of the sweep's software pipeline (draws between a draw's LDS requests and their use)
+#endif
+#ifndef PLA_TILE_MASKED
+#define PLA_TILE_MASKED 0  // list appends under the execution mask (0: every lane, the others on private dump counters / slots)
+#endif
+#ifndef PLA_TILE_ABLATE
+#define PLA_TILE_ABLATE 0  // timing experiments (tools/build_alt.sh): 1 no selection, 2 no sample / threshold, 4 sweep = loads + min only, 8 no list appends, 16 no exponentials
 #endif
 constexpr int kTileWaves = 8;
 constexpr int kTileThreads = kWave * kTileWaves;
 constexpr int kTileSample = 512;
 constexpr int kTileCap = PLA_TILE_CAP;
-constexpr int kTileBisect = 16;
 
 struct TileParams {
   const void* in;      // element (observation i, draw s) at in[s * ld + i]
@@ -85,7 +90,6 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
   constexpr int kStep = kSub * kTileWaves;          // draws per step of the workgroup: 32
   constexpr int kPer = kTileSample / kStep;         // sampled draws per lane: 16
   constexpr int kSelPer = kObs / kTileWaves;        // observations a wave selects for: 2
-  constexpr int U = PLA_TILE_U;
   const int tid = (int)threadIdx.x;
   for (int j = tid; j < kTabN; j += kTileThreads) exp_table_entry(sm.tab, j);
   sm.dumpc[tid] = 0x80000000u;
@@ -97,182 +101,22 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
   const int64_t db = P.ld * (int64_t)sizeof(T);      // bytes between consecutive draws
   const int64_t step_bytes = db * kStep;
   const int nit = S / kStep;                         // whole steps
-  const int nb = nit / U, left = nit - nb * U;       // whole batches, steps behind them
   const int64_t ngroups = (P.n_obs + kObs - 1) / kObs;
   const double INF = pinf();
   const char* tabc = reinterpret_cast<const char*>(sm.tab);
 
-  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
-    const int64_t obs0 = g * kObs;
-    // (lanes past the last observation of the launch re-read the last one; nothing of theirs is selected)
-    const int oc = (obs0 + o < P.n_obs) ? o : (int)(P.n_obs - 1 - obs0);
-    // this lane inside a step: its observation and its draw of the wave's kSub (32-bit: ld < 2^32 / (8 kSub), checked by the launcher)
-    const int voff = (int)((unsigned)(oc * (int)sizeof(T)) + (unsigned)dsub * (unsigned)db);
-    // the wave's first piece of step 0 (scalar)
-    const char* gbase = reinterpret_cast<const char*>(P.in) + obs0 * (int64_t)sizeof(T) + (int64_t)(kSub * w) * db;
-    const auto load_step = [&](int step) {
-      const __amdgpu_buffer_rsrc_t rs =
-          __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(gbase + (int64_t)step * step_bytes), 0, (int)0xfffffff0u, 0x00020000);
-      return col_load<T>(rs, voff, 0);
-    };
-
-    // ---- A. the sample: step floor((j + w / 8) nit / 16) for j < 16 -- 128 clusters of four consecutive draws, evenly spread -----
-    {
-      T sv[kPer];
-#pragma unroll
-      for (int j = 0; j < kPer; ++j) sv[j] = load_step((int)(((int64_t)(kTileWaves * j + w) * nit) / (kTileWaves * kPer)));
-#pragma unroll
-      for (int j = 0; j < kPer; ++j)  // rounded up: the threshold may only err towards FEWER candidates by what one float ulp is worth
-        sm.keys[o][(w * kSub + dsub) * kPer + j] = __double2float_ru(-(double)sv[j]);
-    }
-    __syncthreads();
-    // ---- B. threshold and provisional shift, one wave per observation -------------------------------------------------------
-#pragma unroll 1
-    for (int q = 0; q < kSelPer; ++q) {
-      const int oo = w * kSelPer + q;
-      float kx[kTileSample / kWave];
-      float lmin = __builtin_inff(), lmax = -__builtin_inff();
-#pragma unroll
-      for (int k = 0; k < kTileSample / kWave; ++k) {
-        kx[k] = sm.keys[oo][lane + kWave * k];
-        lmin = fminf(lmin, kx[k]);
-        lmax = fmaxf(lmax, kx[k]);
-      }
-      double hmax, nlmin;
-      wave_all2<R_MAX>((double)lmax, -(double)lmin, hmax, nlmin);
-      float lo = (float)(-nlmin), hi = (float)hmax;
-      const int nbt = kTileSample - P.ks;  // a value with at least this many of the sample below it
-#pragma unroll 1
-      for (int it = 0; it < kTileBisect; ++it) {
-        const float mid = 0.5f * (lo + hi);
-        int below = 0;
-#pragma unroll
-        for (int k = 0; k < kTileSample / kWave; ++k) below += __popcll(__ballot(kx[k] < mid));
-        if (below >= nbt) hi = mid;
-        else lo = mid;
-      }
-      if (lane == 0) {
-        sm.scal[oo][0] = hmax;
-        sm.scal[oo][1] = (double)hi;
-        sm.cnt[oo] = 0u;
-      }
-    }
-    __syncthreads();
-
-    // ---- C. the sweep ---------------------------------------------------------------------------------------------------------
-    const double nmp = -sm.scal[o][0], nt_raw = -sm.scal[o][1];
-    double nmn = INF, nmx = -INF, s1 = 0.0, s2 = 0.0;  // min / max of ll = -(max / min of raw)
-    T* const mylist = sm.list[o];
-    unsigned* const mycnt = &sm.cnt[o];
-    unsigned* const mydumpc = &sm.dumpc[tid];
-    T* const mydumpv = &sm.dumpv[tid];
-    int c4096 = 4096, cm4096 = -4096, four = 4;
-    asm volatile("" : "+s"(c4096), "+s"(cm4096));
-    asm volatile("" : "+v"(four));
-    // Software pipeline, kPF draws deep and carried from batch to batch: stage A of a draw (shift, range reduction, table
-    // read, the request for a list slot) is issued kPF draws before its stage B (polynomial, accumulation, the store to the
-    // slot), so that the LDS round trips of the table read and of the counter are covered by the arithmetic in between.
-    constexpr int kPF = 3;
-    static_assert(U % kPF == 0, "pipeline slots are assigned at compile time");
-    double px[kPF], pt[kPF], pll[kPF];
-    int4 ptt[kPF];
-    unsigned ppos[kPF];
-    const auto stage_a = [&](const double ll, const int sl) {
-      nmn = fmin(nmn, ll);
-      nmx = fmax(nmx, ll);
-      const double x = nmp - ll;                       // raw - m': psis.py:134 about the provisional shift
-      const double t = fma(x, kC256, kMagic);
-      const int k = __double2loint(t);
-      ptt[sl] = *reinterpret_cast<const int4*>(tabc + byte0_shl(k, four));
-      // candidate: a slot of the observation's list from its counter (32 lanes in 8 waves append to one list); everybody else
-      // counts on a private counter that starts past the end of any list, and stores to a private slot: no control flow
-      const bool cand = ll <= nt_raw;                  // raw >= threshold
-      ppos[sl] = __hip_atomic_fetch_add(cand ? mycnt : mydumpc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      px[sl] = x;
-      pt[sl] = t;
-      pll[sl] = ll;
-    };
-    const auto stage_b = [&](const int sl) {
-      const double x = px[sl], t = pt[sl];
-      const int k = __double2loint(t);
-      const double rr = fma(t - kMagic, -kLn2_256, x);
-      const double r2 = rr * rr;
-      const double E = fma(r2, 0.5, 1.0);              // cosh rr to 1.5e-13 (as in the wave kernel's sweep)
-      const double O = fma(1.66666666666666666667e-01, r2, 1.0);
-      s1 = fma(__hiloint2double(mad_i24(k, c4096, ptt[sl].y), ptt[sl].x), fma(rr, O, E), s1);
-      s2 = fma(__hiloint2double(mad_i24(k, cm4096, ptt[sl].w), ptt[sl].z), fma(-rr, O, E), s2);
-      *(ppos[sl] < (unsigned)kTileCap ? &mylist[ppos[sl]] : mydumpv) = (T)pll[sl];
-    };
-    const auto one = [&](double ll) {  // (outside the batches: the few draws behind them)
-      stage_a(ll, 0);
-      stage_b(0);
-    };
-    {
-      T buf[2][U];
-      const auto fetch = [&](T (&dst)[U], int b) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) dst[u] = load_step(b * U + u);
-      };
-      bool primed = false;  // (known at compile time at every call: the first batch has no stage B for its first kPF draws)
-      const auto work = [&](const T (&src)[U], const bool first) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (!(first && u < kPF)) stage_b(u % kPF);
-          stage_a((double)src[u], u % kPF);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      };
-      const auto drain = [&]() {
-#pragma unroll
-        for (int u = 0; u < kPF; ++u) stage_b(u);
-      };
-      if (nb > 0) {
-        fetch(buf[0], 0);
-        if (nb > 1) fetch(buf[1], 1);
-        work(buf[0], true);  // (the only copy of the loop body without the first stage Bs)
-        primed = true;
-      }
-      int b = 1;
-#pragma unroll 1
-      for (; b + 2 <= nb; b += 2) {
-        fetch(buf[0], b + 1);
-        work(buf[1], false);
-        if (b + 2 < nb) fetch(buf[1], b + 2);
-        work(buf[0], false);
-      }
-      if (b < nb) work(buf[1], false);  // an even number of batches: the last one is already fetched
-      if (primed) drain();
-      // the steps behind the last whole batch, and the draws behind the last whole step
-      if (left > 0) {
-#pragma unroll
-        for (int u = 0; u < U - 1; ++u)
-          if (u < left) buf[0][u] = load_step(nb * U + u);
-#pragma unroll
-        for (int u = 0; u < U - 1; ++u)
-          if (u < left) one((double)buf[0][u]);
-      }
-      if (nit * kStep + kSub * w + dsub < S) one((double)load_step(nit));
-    }
-    // ---- the 32 lanes of an observation: the four of a wave here, the eight waves in LDS ---------------------------------------
-#pragma unroll
-    for (int off = kObs; off < kWave; off *= 2) {
-      nmn = fmin(nmn, __shfl_xor(nmn, off));
-      nmx = fmax(nmx, __shfl_xor(nmx, off));
-      s1 += __shfl_xor(s1, off);
-      s2 += __shfl_xor(s2, off);
-    }
-    if (dsub == 0) {
-      double* rd = sm.red[w][o];
-      rd[0] = nmn; rd[1] = nmx; rd[2] = s1; rd[3] = s2;
-    }
-    __syncthreads();
-
-    // ---- D. selection: wave w takes the observations kSelPer w + q ---------------------------------------------------------------
+  // ---- D. selection of group gp on its lists in LDS: wave w takes the observations kSelPer w + q -----------------------------
+  const auto select_group = [&](const int64_t gp) {
+    const int64_t obs0 = gp * kObs;
 #pragma unroll 1
     for (int q = 0; q < kSelPer; ++q) {
       const int oo = w * kSelPer + q;
       const int64_t r = obs0 + oo;
       if (r >= P.n_obs) break;  // (wave-uniform)
+      if constexpr ((PLA_TILE_ABLATE & 1) != 0) {
+        if (lane == 0) F.ws_s[r * F.ws_sstride + 5] = sm.red[0][oo][0] + sm.red[0][oo][2] + (double)sm.cnt[oo];
+        continue;
+      }
       double lmin = INF, lmax = -INF, s1p = 0.0, s2p = 0.0;
 #pragma unroll
       for (int k = 0; k < kTileWaves; ++k) {  // (every lane reads the same eight entries: broadcasts, and one order of summation)
@@ -311,13 +155,300 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
         wave_select_split<typename SMT::Sel, SMT, (CapsSmall::kMaxTail + 63) / 64, CandInTile<T>>(
             F, ss, sm, r, lane, M, m, mn, s1, s2, (unsigned)ncand, k1, sh, magic, c256, slow, src);
       }
-      if (slow && lane == 0) {
-        const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
-        F.slow_list[idx] = (unsigned)r + F.slow_base;
-        F.ws_s[r * F.ws_sstride + 5] = -1.0;  // tail length -1: on the list, nothing for the fit kernel
+      // (a scalar branch: the wait for the counter's old value must not lie on the path of the observations that stay -- it
+      // would also wait for the next group's loads, which are in flight through this selection)
+      if (__builtin_amdgcn_readfirstlane((int)slow) != 0 && PLA_TILE_ABLATE == 0) {
+        if (lane == 0) {
+          const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
+          F.slow_list[idx] = (unsigned)r + F.slow_base;
+          F.ws_s[r * F.ws_sstride + 5] = -1.0;  // tail length -1: on the list, nothing for the fit kernel
+        }
       }
     }
-    __syncthreads();  // the lists are free for the next group's sample
+  };
+  const auto sample_step = [&](int j) { return (int)(((int64_t)(kTileWaves * j + w) * nit) / (kTileWaves * kPer)); };
+  // One trip of the loop: the sample loads of group g are ISSUED, the selection of the group before it runs on the lists in LDS
+  // while they fly, then the sample is turned into thresholds and the group is swept.  (One place of issue for the sample; the
+  // loop is entered with no group behind and left with none ahead.)
+  int64_t g = blockIdx.x, prev = -1;
+  for (;;) {
+    const bool have = g < ngroups;
+    const int64_t obs0 = g * kObs;
+    // (lanes past the last observation of the launch re-read the last one; nothing of theirs is selected)
+    const int oc = (obs0 + o < P.n_obs) ? o : (int)(P.n_obs - 1 - obs0);
+    // this lane inside a step: its observation and its draw of the wave's kSub (32-bit: ld < 2^32 / (8 kSub), checked by the launcher)
+    const int voff = (int)((unsigned)(oc * (int)sizeof(T)) + (unsigned)dsub * (unsigned)db);
+    // the wave's first piece of step 0 (scalar)
+    const char* gbase = reinterpret_cast<const char*>(P.in) + obs0 * (int64_t)sizeof(T) + (int64_t)(kSub * w) * db;
+    const auto load_step = [&](int step) {
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(gbase + (int64_t)step * step_bytes), 0, (int)0xfffffff0u, 0x00020000);
+      return col_load<T>(rs, voff, 0);
+    };
+    // ---- A. the sample: step floor((j + w / 8) nit / 16) for j < 16 -- 128 clusters of four consecutive draws, evenly spread -----
+    T sv[kPer];
+    if (have && !(PLA_TILE_ABLATE & 2)) {
+#pragma unroll
+      for (int j = 0; j < kPer; ++j) sv[j] = load_step(sample_step(j));
+    }
+    // ... and the first R steps of the sweep's ring behind them: in flight through the selection and the threshold search,
+    // so that the sweep starts on a full pipeline
+    // (steps past the row: the last whole step again -- a harmless hit in the cache; what they load is never looked at)
+    constexpr int R = PLA_TILE_RING;
+    T ring[R];
+    const int last = nit - 1;
+    if (have) {
+#pragma unroll
+      for (int u = 0; u < R; ++u) ring[u] = load_step(u < last ? u : last);
+    }
+    if (prev >= 0) select_group(prev);
+    if (!have) break;
+    __syncthreads();  // the lists of the group before are free for this group's sample
+    if constexpr (!(PLA_TILE_ABLATE & 2)) {
+#pragma unroll
+      for (int j = 0; j < kPer; ++j)  // rounded up: the threshold may only err towards FEWER candidates by what one float ulp is worth
+        sm.keys[o][(w * kSub + dsub) * kPer + j] = __double2float_ru(-(double)sv[j]);
+      __syncthreads();
+      // ---- B. threshold and provisional shift: a wave per observation, kSelPer observations side by side ------------------------
+      // The sample's ks-th largest value to 1/4096 of the sample's range, by counting: a 64-bin histogram of the eight keys a
+      // lane holds (one bin per lane, LDS atomics), a suffix sum over the lanes, the bin that holds the ks-th largest -- and the
+      // same again inside that bin.  (Bisection on ballot counts, 12 halvings x 8 compares per observation, was a fifth of
+      // the instructions of the whole sweep.)  The threshold is the lower edge of the final sub-bin: ks .. ks + (members of
+      // that sub-bin) - 1 of the sample lie at or above it.
+      constexpr int KX = kTileSample / kWave;
+      float kx[kSelPer][KX], hi[kSelPer];
+      double hmax[kSelPer];
+      unsigned* const hh = sm.sel[w].hist;  // (the selection's scratch is idle here) [level][observation][64] + 64 dump words
+      {
+        const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+        static_assert(kWaveBins >= 4 * kWave * kSelPer / 2 + kWave, "histograms of the threshold search fit the selection's");
+        *reinterpret_cast<uint4*>(&hh[4 * lane]) = z4;  // 256 words: two levels x two observations
+      }
+      float lo1[kSelPer], w1[kSelPer];
+      int bin[kSelPer][KX];
+#pragma unroll
+      for (int q = 0; q < kSelPer; ++q) {
+        float lmin = __builtin_inff(), lmax = -__builtin_inff();
+#pragma unroll
+        for (int k = 0; k < KX; ++k) {
+          kx[q][k] = sm.keys[w * kSelPer + q][lane + kWave * k];
+          lmin = fminf(lmin, kx[q][k]);
+          lmax = fmaxf(lmax, kx[q][k]);
+        }
+        double nlmin;
+        wave_all2<R_MAX>((double)lmax, -(double)lmin, hmax[q], nlmin);
+        lo1[q] = (float)(-nlmin);
+        w1[q] = ((float)hmax[q] - lo1[q]) * (1.0f / 64.0f);
+      }
+      wave_sync();
+      const auto level = [&](const int lv, const float (&lo)[kSelPer], const float (&wd)[kSelPer], const int (&want)[kSelPer],
+                             const int (&only)[kSelPer], int (&bstar)[kSelPer], int (&need)[kSelPer]) {
+#pragma unroll
+        for (int q = 0; q < kSelPer; ++q) {
+          const float sc = 1.0f / wd[q];
+          unsigned* const h = hh + (lv * kSelPer + q) * kWave;
+#pragma unroll
+          for (int k = 0; k < KX; ++k) {
+            int b = (int)((kx[q][k] - lo[q]) * sc);
+            b = b < 0 ? 0 : (b > kWave - 1 ? kWave - 1 : b);
+            const bool in = lv == 0 || bin[q][k] == only[q];
+            if (lv == 0) bin[q][k] = b;
+            atomicAdd(in ? &h[b] : &hh[2 * kSelPer * kWave + lane], 1u);
+          }
+        }
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < kSelPer; ++q) {
+          const unsigned c = hh[(lv * kSelPer + q) * kWave + lane];
+          unsigned pre = c;  // inclusive prefix over the lanes
+          pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0x111, 0xF, 0xF, true);     // row_shr:1
+          pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0x112, 0xF, 0xF, true);     // row_shr:2
+          pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0x113, 0xF, 0xF, true);     // row_shr:3
+          pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x114, 0xF, 0xE, false);  // row_shr:4, banks 1-3
+          pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x118, 0xF, 0xC, false);  // row_shr:8, banks 2-3
+          pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x142, 0xA, 0xF, false);  // row_bcast:15
+          pre += (unsigned)__builtin_amdgcn_update_dpp(0, (int)pre, 0x143, 0xC, 0xF, false);  // row_bcast:31
+          const unsigned all = (unsigned)__builtin_amdgcn_readlane((int)pre, kWave - 1);
+          const int above = (int)(all - pre);  // members of the higher bins
+          // the bin that holds the want-th largest; none does when fewer than `want` are counted at all (then: the lowest bin)
+          const unsigned long long who = __ballot(above < want[q] && want[q] <= above + (int)c);
+          const int src = who ? __ffsll((long long)who) - 1 : 0;
+          bstar[q] = src;
+          need[q] = want[q] - __builtin_amdgcn_readlane(above, src);
+        }
+      };
+      int want1[kSelPer], none[kSelPer], b1[kSelPer], need1[kSelPer], b2[kSelPer], need2[kSelPer];
+      float lo2[kSelPer], w2[kSelPer];
+#pragma unroll
+      for (int q = 0; q < kSelPer; ++q) {
+        want1[q] = P.ks;
+        none[q] = 0;
+      }
+      level(0, lo1, w1, want1, none, b1, need1);
+#pragma unroll
+      for (int q = 0; q < kSelPer; ++q) {
+        lo2[q] = fmaf((float)b1[q], w1[q], lo1[q]);
+        w2[q] = w1[q] * (1.0f / 64.0f);
+      }
+      level(1, lo2, w2, need1, b1, b2, need2);
+#pragma unroll
+      for (int q = 0; q < kSelPer; ++q) hi[q] = fmaf((float)b2[q], w2[q], lo2[q]);
+      wave_sync();
+      if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < kSelPer; ++q) {
+          sm.scal[w * kSelPer + q][0] = hmax[q];
+          sm.scal[w * kSelPer + q][1] = (double)hi[q];
+          sm.cnt[w * kSelPer + q] = 0u;
+        }
+      }
+    } else if (tid < kObs) {
+      sm.scal[tid][0] = 0.0;
+      sm.scal[tid][1] = 1e300;
+      sm.cnt[tid] = 0u;
+    }
+    __syncthreads();
+
+    // ---- C. the sweep ---------------------------------------------------------------------------------------------------------
+    const double nmp = -sm.scal[o][0], nt_raw = -sm.scal[o][1];
+    double nmn = INF, nmx = -INF, s1 = 0.0, s2 = 0.0;  // min / max of ll = -(max / min of raw)
+    T* const mylist = sm.list[o];
+    unsigned* const mycnt = &sm.cnt[o];
+    unsigned* const mydumpc = &sm.dumpc[tid];
+    T* const mydumpv = &sm.dumpv[tid];
+    // the constants of the sweep live in registers for its whole length (MachineLICM is off for this library: the compiler
+    // would otherwise re-materialise each of them with s_mov per use -- ten scalar instructions per draw)
+    int c4096 = 4096, cm4096 = -4096, four = 4;
+    double c256 = kC256, magic = kMagic, nmagic = -kMagic, nl256 = -kLn2_256, c6 = 1.66666666666666666667e-01;
+    asm volatile("" : "+s"(c4096), "+s"(cm4096), "+s"(c256), "+s"(nl256), "+s"(c6));
+    asm volatile("" : "+v"(four), "+v"(magic), "+v"(nmagic));
+    // Software pipeline, kPF draws deep and carried from batch to batch: stage A of a draw (shift, range reduction, table
+    // read, the request for a list slot) is issued kPF draws before its stage B (polynomial, accumulation, the store to the
+    // slot), so that the LDS round trips of the table read and of the counter are covered by the arithmetic in between.
+    constexpr int kPF = PLA_TILE_PF;
+    double px[kPF], pt[kPF], pll[kPF];
+    int4 ptt[kPF];
+    unsigned ppos[kPF];
+    const auto stage_a = [&](const double ll, const int sl) {
+      nmn = vmin_nc(nmn, ll);
+      if constexpr ((PLA_TILE_ABLATE & 4) != 0) return;                          // (a NaN draw is ignored here and poisons the sums: general kernel)
+      nmx = vmax_nc<false>(nmx, ll);
+      const double x = nmp - ll;                       // raw - m': psis.py:134 about the provisional shift
+      const double t = fma(x, c256, magic);
+      const int k = __double2loint(t);
+      ptt[sl] = *reinterpret_cast<const int4*>(tabc + byte0_shl(k, four));
+      // candidate: a slot of the observation's list from its counter (32 lanes in 8 waves append to one list); everybody else
+      // counts on a private counter that starts past the end of any list, and stores to a private slot: no control flow
+      const bool cand = ll <= nt_raw;                  // raw >= threshold
+      if constexpr ((PLA_TILE_ABLATE & 8) != 0) {
+        nmx = vmax_nc<false>(nmx, cand ? 1.0 : 2.0);
+      } else if constexpr (PLA_TILE_MASKED != 0) {
+        // only the lanes that hold a candidate (one in ten) take part in the atomic: the LDS serves an atomic lane by lane
+        unsigned pos = 0xffffffffu;
+        if (cand) pos = __hip_atomic_fetch_add(mycnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ppos[sl] = pos;
+      } else if constexpr ((PLA_TILE_ABLATE & 64) != 0) {
+        ppos[sl] = cand ? 0xffffffffu : 0xfffffff0u;
+      } else {
+        ppos[sl] = __hip_atomic_fetch_add(cand ? mycnt : mydumpc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      px[sl] = x;
+      pt[sl] = t;
+      // (an explicit copy: the ring slot this draw came from is dead from here on, so that the load issued right behind this
+      // stage lands in the slot's own registers -- left to itself the compiler keeps the draw where it is, loads into spare
+      // registers and moves them home at the end of the round behind an s_waitcnt vmcnt(1) that drains the whole ring)
+      asm("v_mov_b64 %0, %1" : "=v"(pll[sl]) : "v"(ll));
+    };
+    const auto stage_b = [&](const int sl) {
+      if constexpr ((PLA_TILE_ABLATE & 4) != 0) return;
+      if constexpr ((PLA_TILE_ABLATE & 16) != 0) {
+        s1 += px[sl];
+        if constexpr (!(PLA_TILE_ABLATE & 8)) *(ppos[sl] < (unsigned)kTileCap ? &mylist[ppos[sl]] : mydumpv) = (T)pll[sl];
+        return;
+      }
+      const double x = px[sl], t = pt[sl];
+      const int k = __double2loint(t);
+      const double rr = fma(t + nmagic, nl256, x);
+      const double r2 = rr * rr;
+      const double E = fma(r2, 0.5, 1.0);              // cosh rr to 1.5e-13 (as in the wave kernel's sweep)
+      const double O = fma(c6, r2, 1.0);
+      s1 = fma(__hiloint2double(mad_i24(k, c4096, ptt[sl].y), ptt[sl].x), fma(rr, O, E), s1);
+      s2 = fma(__hiloint2double(mad_i24(k, cm4096, ptt[sl].w), ptt[sl].z), fma(-rr, O, E), s2);
+      if constexpr (!(PLA_TILE_ABLATE & 8)) {
+        if constexpr (PLA_TILE_MASKED != 0) {
+          if (ppos[sl] < (unsigned)kTileCap) mylist[ppos[sl]] = (T)pll[sl];
+        } else if constexpr ((PLA_TILE_ABLATE & 32) != 0) {
+          nmx = vmax_nc<false>(nmx, ppos[sl] < (unsigned)kTileCap ? 1.0 : 2.0);
+        } else {
+          *(ppos[sl] < (unsigned)kTileCap ? &mylist[ppos[sl]] : mydumpv) = (T)pll[sl];
+        }
+      }
+    };
+    const auto one = [&](double ll) {  // (outside the batches: the few draws behind them)
+      stage_a(ll, 0);
+      stage_b(0);
+    };
+    {
+      // The stream: a ring of R steps per lane.  The load of step i + R is issued into the slot of step i as soon as that
+      // draw has entered the pipeline, so R - kPF loads per lane are in flight at every moment (two half-rings that are
+      // fetched and consumed in turn keep only one of them in flight while the other is computed on: at two waves per SIMD
+      // that left the sweep waiting on HBM latency, 48 KB per CU outstanding where ~100 KB are needed).
+      static_assert(R % kPF == 0, "pipeline slots are assigned at compile time");
+      const int nmain = (nit / R) * R;
+      const char* ahead = gbase + (int64_t)R * step_bytes;   // where step base + R + u lies
+      const char* const endp = gbase + (int64_t)last * step_bytes;
+      int rs_records = (int)0xfffffff0u, rs_flags = 0x00020000;
+      asm volatile("" : "+s"(rs_records), "+s"(rs_flags));
+      // (the pipeline starts on kPF draws that count nothing: table entry 0 x 2^0 = 0.0 times a polynomial of 1, stored to the dump slot)
+#pragma unroll
+      for (int u = 0; u < kPF; ++u) {
+        px[u] = 0.0;
+        pt[u] = kMagic;
+        pll[u] = 0.0;
+        ptt[u] = make_int4(0, 0, 0, 0);
+        ppos[u] = 0xffffffffu;
+      }
+#pragma unroll 1
+      for (int base = 0; base < nmain; base += R) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          stage_b(u % kPF);
+          stage_a((double)ring[u], u % kPF);
+          // the step R ahead, through a running pointer (the last whole step again once the row is through)
+          const bool in = base + (R + u) < last;
+          const char* at = in ? ahead : endp;
+          asm volatile("" : "+s"(at));
+          ring[u] = col_load<T>(__builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(at), 0, rs_records, rs_flags), voff, 0);
+          ahead += step_bytes;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kPF; ++u) stage_b(u);
+      // the steps behind the last whole round (already in the ring), and the draws behind the last whole step
+      const int left_steps = nit - nmain;
+      if (left_steps > 0) {
+#pragma unroll
+        for (int u = 0; u < R - 1; ++u)
+          if (u < left_steps) one((double)ring[u]);
+      }
+      if (nit * kStep + kSub * w + dsub < S) one((double)load_step(nit));
+    }
+    // ---- the 32 lanes of an observation: the four of a wave here, the eight waves in LDS ---------------------------------------
+#pragma unroll
+    for (int off = kObs; off < kWave; off *= 2) {
+      nmn = fmin(nmn, __shfl_xor(nmn, off));
+      nmx = fmax(nmx, __shfl_xor(nmx, off));
+      s1 += __shfl_xor(s1, off);
+      s2 += __shfl_xor(s2, off);
+    }
+    if (dsub == 0) {
+      double* rd = sm.red[w][o];
+      rd[0] = nmn; rd[1] = nmx; rd[2] = s1; rd[3] = s2;
+    }
+    __syncthreads();
+    prev = g;
+    g += gridDim.x;
   }
 }
 

@@ -77,6 +77,54 @@ __global__ __launch_bounds__(64 * WAVES) void v1(const double* in, int64_t n_obs
     if (acc == 12345.678) out[i] = acc;
   }
 }
+// V2: a workgroup of 4 waves owns 8 neighbouring observations (a 64-byte piece of a draw); lane = (observation l & 7, draw l >> 3).
+// PAIR: the two halves of a 128-byte line go to two workgroups of the same XCD (blockIdx % 8) that run side by side.
+template <bool PAIR>
+__global__ __launch_bounds__(256) void v2(const double* in, int64_t n_obs, int S, int64_t ld, double* out) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int step = 32;
+  const int64_t db = ld * 8;
+  const int64_t ngroups = n_obs / 8;
+  const int b = blockIdx.x, grid = gridDim.x;
+  for (int64_t j = 0;; ++j) {
+    int64_t g;
+    if (PAIR) {
+      const int xcd = b & 7, slot = b >> 3;
+      g = 2 * ((int64_t)(slot >> 1) * 8 + xcd + j * (grid / 2)) + (slot & 1);
+    } else {
+      g = b + j * grid;
+    }
+    if (g >= ngroups) break;
+    const int64_t i = g * 8 + (lane & 7);
+    const int d0 = 8 * w + (lane >> 3);
+    const unsigned voff = (unsigned)((i - g * 8) * 8) + (unsigned)(d0 * db);
+    const char* gb = (const char*)in + g * 64;
+    double acc = 0.0, buf[2][U];
+    const int nb = S / (U * step);
+    auto fetch = [&](double (&d)[U], int bb) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((char*)gb + (int64_t)(bb * U + u) * step * db, 0, (int)0xfffffff0u, 0x00020000);
+        d[u] = ld64(rs, (int)voff, 0);
+      }
+    };
+    auto work = [&](const double (&d)[U]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc += d[u];
+    };
+    fetch(buf[0], 0);
+    int bb = 0;
+#pragma unroll 1
+    for (; bb + 2 <= nb; bb += 2) {
+      fetch(buf[1], bb + 1);
+      work(buf[0]);
+      if (bb + 2 < nb) fetch(buf[0], bb + 2);
+      work(buf[1]);
+    }
+    if (bb < nb) work(buf[0]);
+    if (acc == 12345.678) out[i] = acc;
+  }
+}
 int main(int argc, char** argv) {
   const int64_t n = argc > 1 ? atoll(argv[1]) : 1000000;
   const int S = argc > 2 ? atoi(argv[2]) : 4000;
@@ -104,5 +152,7 @@ int main(int argc, char** argv) {
   run("v1 tile 16 obs, 4 waves, 512 persistent", [&] { hipLaunchKernelGGL(v1<4>, dim3(512), dim3(256), 0, 0, in, n, S, n, out); });
   run("v1 tile 16 obs, 4 waves, 1024 persistent", [&] { hipLaunchKernelGGL(v1<4>, dim3(1024), dim3(256), 0, 0, in, n, S, n, out); });
 
+  run("v2 tile 8 obs (64 B pieces), 4 waves, 512 persistent", [&] { hipLaunchKernelGGL(v2<false>, dim3(512), dim3(256), 0, 0, in, n, S, n, out); });
+  run("v2 tile 8 obs (64 B pieces), 4 waves, 512, XCD pairs", [&] { hipLaunchKernelGGL(v2<true>, dim3(512), dim3(256), 0, 0, in, n, S, n, out); });
   return 0;
 }
