@@ -522,8 +522,13 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
   const bool col_offsets_fit = (double)stride_draw * (double)esz * 16.0 + (double)kColBlock * (double)esz < 2147483648.0;
   const bool use_col = ingest && method == PLA_PSIS && !force_transpose && col_offsets_fit &&
                        pla::col_supported((int)n_draws, (int)tail_count, &col_kq);
+  // ... a workgroup per 16 observations (pla_tile.h), streamed (the fit kernel beside it, PLA_PIPE=0: back to back) where the
+  // shorter lists of the streamed pass still leave room around the expected candidate count
+  const char* pipe_env0 = getenv("PLA_PIPE");
   int tile_ks = 0;
-  const bool use_tile = use_col && pla::tile_supported(dtype, (int)n_draws, (int)tail_count, stride_draw, &tile_ks);
+  bool tile_stream = !(pipe_env0 && atoi(pipe_env0) == 0) && use_col && mem_space == PLA_DEVICE &&
+                     pla::tile_supported(dtype, (int)n_draws, (int)tail_count, stride_draw, true, &tile_ks);
+  const bool use_tile = tile_stream || (use_col && pla::tile_supported(dtype, (int)n_draws, (int)tail_count, stride_draw, false, &tile_ks));
   // Streamed split pass (device-resident, draws-fastest matrices): the fit kernel runs BESIDE the wave kernel, in the registers
   // and LDS that kernel leaves free on a CU, and takes the chunks of observations as they are finished (pla_kernels.hip,
   // launch_wave).  PLA_PIPE=0: the two kernels back to back on the caller's stream (round 2's arrangement; A/B runs).
@@ -565,13 +570,14 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
           q.ws_sstride = 16;
           pipeline = pla::rows_stream_planned(q, dtype);
         }
-        if (pipeline) {
+        if (tile_stream && !(stride <= 256)) tile_stream = false;
+        if (pipeline || tile_stream) {
           rc = ensure_pipe(eng);
           if (rc) return rc;
           rc = grow(&eng->d_sync, &eng->d_sync_bytes, pla::stream_sync_bytes(rows));
           if (rc) return rc;
         }
-        const int sstride = pipeline ? 16 : 8;  // (streamed: one whole 128-byte line of scalars per observation)
+        const int sstride = (pipeline || tile_stream) ? 16 : 8;  // (streamed: one whole 128-byte line of scalars per observation)
         rc = grow(&eng->d_ws, &eng->d_ws_bytes, (size_t)rows * (size_t)(stride + sstride) * sizeof(double));
         if (rc == PLA_ERR_NOMEM && !use_col) {
           rc = 0;  // no room for the hand-over: the fused kernels need none (the split pass is the faster, not the only, path)
@@ -585,9 +591,11 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
       }
     }
   }
-  if (!p.ws_y) pipeline = false;
+  if (!p.ws_y) pipeline = tile_stream = false;
+  if (!use_tile) tile_stream = false;
+  if (use_tile && !tile_stream) (void)pla::tile_supported(dtype, (int)n_draws, (int)tail_count, stride_draw, false, &tile_ks);  // (the longer lists' threshold)
   // [1]: rows left to the general kernel (a streamed pass zeroes the counters together with its flags: one command less)
-  if (!pipeline) PLA_HIP(hipMemsetAsync(eng->counters, 0, 16 * sizeof(unsigned long long), s));
+  if (!pipeline && !tile_stream) PLA_HIP(hipMemsetAsync(eng->counters, 0, 16 * sizeof(unsigned long long), s));
 
   if (mem_space == PLA_DEVICE) {
     // agg needs the pointwise loo_i: use the caller's vectors, or the engine scratch
@@ -613,8 +621,16 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
         p.diag = dd ? dd + r0 : nullptr;
         p.loo_i = dl ? dl + r0 : nullptr;
         p.lppd_i = dp ? dp + r0 : nullptr;
-        PLA_HIP(pla::launch_tile(p, dtype, tile_ks, s));
-        eng->last_kernels = "tile_loo_kernel (a workgroup per 16 observations, matrix read in place) + fit_rows_kernel + slow_rows_kernel";
+        if (tile_stream) {
+          pla::PipeStreams ps{eng->pipe_first, eng->pipe_second, eng->pipe_fork, eng->pipe_join1, eng->pipe_join2, (unsigned*)eng->d_sync,
+                              nullptr, nullptr, r0 == 0};
+          PLA_HIP(pla::launch_tile(p, dtype, tile_ks, s, &ps));
+          eng->last_kernels = "tile_loo_kernel<SYNC> (a workgroup per 16 observations, matrix read in place) with fit_rows_stream_kernel beside it "
+                              "on a second stream + fit_rows_kernel (leftovers) + slow_rows_kernel";
+        } else {
+          PLA_HIP(pla::launch_tile(p, dtype, tile_ks, s));
+          eng->last_kernels = "tile_loo_kernel (a workgroup per 16 observations, matrix read in place) + fit_rows_kernel + slow_rows_kernel";
+        }
       }
       if (agg) {
         pla::ReduceParams rp{dd, dl, dp, n_obs, good_k, agg, eng->counters + 1};

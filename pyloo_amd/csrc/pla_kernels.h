@@ -109,8 +109,10 @@ size_t col_workspace_bytes(int64_t n_obs);
 hipError_t launch_col(const RowsParams& p, int dtype, int kq, void* col_ws, hipStream_t stream);
 // ... a workgroup per 16 observations, candidate lists in LDS (pla_tile.h): f64 matrices, 512 <= n_draws, tail counts <= 250 and a
 // list capacity that leaves room on both sides of the expected candidate count.  No workspace beyond the split pass's hand-over.
-bool tile_supported(int dtype, int n_draws, int tail_count, int64_t ld, int* ks);
-hipError_t launch_tile(const RowsParams& p, int dtype, int ks, hipStream_t stream);
+// streamed (pipe with its flags, ws_sstride 16): the fit kernel runs beside the tile kernel, as in the streamed pass of the row kernels;
+// the lists are shorter then (the fit kernel's workgroup needs its share of the CU's LDS), so `streamed` goes into the shape test.
+bool tile_supported(int dtype, int n_draws, int tail_count, int64_t ld, bool streamed, int* ks);
+hipError_t launch_tile(const RowsParams& p, int dtype, int ks, hipStream_t stream, const PipeStreams* pipe = nullptr);
 // WAIC on an observations-fastest matrix read in place, one lane per observation (element (i, s) at in[s * ld + i])
 hipError_t launch_waic_col(const void* in, int dtype, int64_t n_obs, int n_draws, int64_t ld, double scale_value, double* lppd_i,
                            double* var_i, double* waic_i, unsigned long long* replaced, hipStream_t stream);

@@ -785,27 +785,36 @@ hipError_t launch_col(const RowsParams& p, int dtype, int kq, void* col_ws, hipS
 // standard deviation of sqrt(S^2 p (1 - p) / 512 + S p (1 - p)), p = T / S (the sample's quantile, then the row's count given the
 // quantile).  T sits halfway between the M + 1 the selection needs and the list's capacity; shapes where that leaves less than
 // 3.0 standard deviations on either side stay with the lane-per-observation kernels (pla_col.h).
-bool tile_supported(int dtype, int n_draws, int tail_count, int64_t ld, int* ks) {
+bool tile_supported(int dtype, int n_draws, int tail_count, int64_t ld, bool streamed, int* ks) {
   static const int off = debug_flag("PLA_NO_TILE");
   if (off || dtype != PLA_F64) return false;
   if (n_draws < kTileSample || tail_count > CapsSmall::kMaxTail || tail_count < 1) return false;
   if ((double)ld * 8.0 * 4.0 >= 4294967296.0) return false;  // the lane's draw inside a step rides in a 32-bit offset
-  const double target = 0.5 * (tail_count + 1 + kTileCap);
+  const int cap = streamed ? kTileCapStream : kTileCap;
+  const double need = streamed ? 2.9 : 3.0;  // (the streamed pass has the shorter lists: it pays for itself down to here)
+  const double target = 0.5 * (tail_count + 1 + cap);
   int k = (int)std::lround(target * kTileSample / n_draws);
   if (k < 2) return false;
   if (k > kTileSample - 1) k = kTileSample - 1;   // (short rows: nearly every draw is a candidate, and fits)
   const double p = (double)k / kTileSample, T = p * n_draws;
   const double sd = std::sqrt((double)n_draws * n_draws * p * (1 - p) / kTileSample + n_draws * p * (1 - p));
-  if (n_draws > kTileCap && (T - (tail_count + 1) < 3.0 * sd || kTileCap - T < 3.0 * sd)) return false;
-  if (n_draws <= kTileCap && T - (tail_count + 1) < 3.0 * sd) return false;
+  if (n_draws > cap && (T - (tail_count + 1) < need * sd || cap - T < need * sd)) return false;
+  if (n_draws <= cap && T - (tail_count + 1) < need * sd) return false;
   *ks = k;
   return true;
 }
 
-hipError_t launch_tile(const RowsParams& p, int dtype, int ks, hipStream_t stream) {
+template <bool SYNC>
+static bool tile_lds_attr() {
+  using SMT = TileSmem<double, SYNC ? kTileCapStream : kTileCap>;
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_loo_kernel<double, SYNC>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SMT)) == hipSuccess;
+  return ok;
+}
+
+hipError_t launch_tile(const RowsParams& p, int dtype, int ks, hipStream_t stream, const PipeStreams* pipe) {
   if (p.n_obs <= 0) return hipSuccess;
-  hipError_t e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
-  if (e != hipSuccess) return e;
+  hipError_t e = hipSuccess;
   int root_ = (int)std::sqrt((double)p.tail_count);
   while (root_ * root_ > p.tail_count) --root_;
   while ((root_ + 1) * (root_ + 1) <= p.tail_count) ++root_;
@@ -816,20 +825,58 @@ hipError_t launch_tile(const RowsParams& p, int dtype, int ks, hipStream_t strea
   f.ws_s = p.ws_s;
   f.ws_stride = p.ws_stride;
   f.ws_sstride = p.ws_sstride;
-  static const bool attr_set = [] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_loo_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)sizeof(TileSmem<double>)) == hipSuccess;
-  }();
-  if (!attr_set) return hipErrorInvalidValue;
   const int64_t ngroups = (p.n_obs + 15) / 16;
   static const int grid_env = debug_flag("PLA_TILE_GRID");
-  const int64_t cap = grid_env > 0 ? grid_env : 256;  // one workgroup per CU (144 KB of LDS each)
+  const int64_t cap = grid_env > 0 ? grid_env : 256;  // one workgroup per CU
   const unsigned g1 = (unsigned)(ngroups < cap ? ngroups : cap);
-  hipLaunchKernelGGL(tile_loo_kernel<double>, dim3(g1), dim3(kTileThreads), sizeof(TileSmem<double>), stream, c, f, p.tail_count);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  e = launch_fit(p, f, mestM, stream);
-  if (e != hipSuccess) return e;
+  const bool streamed = pipe && pipe->sync && p.ws_sstride == 16 && p.ws_stride <= 256 && p.n_obs < ((int64_t)1 << 31) && split_ok(p, mestM);
+  if (streamed) {
+    // streamed: the fit kernel runs beside the tile kernel and takes each group of 16 observations as its flag goes up
+    // (launch_wave, streamed branch: the same flags, streams and leftovers)
+    if (!tile_lds_attr<true>()) return hipErrorInvalidValue;
+    unsigned* const sync = pipe->sync;
+    const int64_t nchunks = (p.n_obs + kQueueChunk - 1) / kQueueChunk;
+    {
+      const size_t nsync = stream_sync_bytes(p.n_obs) / sizeof(unsigned);
+      const unsigned zg = (unsigned)((nsync + 1023) / 1024 < 256 ? (nsync + 1023) / 1024 : 256);
+      hipLaunchKernelGGL(zero2_kernel, dim3(zg ? zg : 1), dim3(256), 0, stream, reinterpret_cast<unsigned*>(p.counters),
+                         (size_t)(pipe->zero_all_counters ? 32 : 2), sync, nsync);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(pipe->fork, stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(pipe->first, pipe->fork, 0);
+    if (e == hipSuccess) e = hipStreamWaitEvent(pipe->second, pipe->fork, 0);
+    if (e != hipSuccess) return e;
+    f.done = sync + 48;
+    static const char* wprio = getenv("PLA_WAVE_PRIO");
+    f.prio = wprio ? atoi(wprio) : 3;
+    if (pipe->before_first) (void)hipEventRecord(pipe->before_first, pipe->first);
+    hipLaunchKernelGGL((tile_loo_kernel<double, true>), dim3(g1), dim3(kTileThreads), sizeof(TileSmem<double, kTileCapStream>), pipe->first,
+                       c, f, p.tail_count);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (pipe->after_first) (void)hipEventRecord(pipe->after_first, pipe->first);
+    e = launch_fit_stream(p, f, mestM, sync, pipe->second);
+    if (e == hipSuccess) e = launch_fit_stream(p, f, mestM, sync, pipe->first, true);
+    if (e == hipSuccess) e = hipEventRecord(pipe->join_first, pipe->first);
+    if (e == hipSuccess) e = hipEventRecord(pipe->join_second, pipe->second);
+    if (e == hipSuccess) e = hipStreamWaitEvent(stream, pipe->join_first, 0);
+    if (e == hipSuccess) e = hipStreamWaitEvent(stream, pipe->join_second, 0);
+    if (e != hipSuccess) return e;
+    // whatever the streamed fit left (nothing, unless it gave up waiting for the tile kernel)
+    e = launch_fit(p, f, mestM, stream, sync + 48 + nchunks, sync + 32);
+    if (e != hipSuccess) return e;
+  } else {
+    e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    if (!tile_lds_attr<false>()) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((tile_loo_kernel<double, false>), dim3(g1), dim3(kTileThreads), sizeof(TileSmem<double, kTileCap>), stream, c, f,
+                       p.tail_count);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = launch_fit(p, f, mestM, stream);
+    if (e != hipSuccess) return e;
+  }
   // rows the tile kernel declined: the general kernel walks them with the matrix's strides
   constexpr int BLOCK = 256;
   int64_t g3 = p.n_obs < 1024 ? p.n_obs : 1024;

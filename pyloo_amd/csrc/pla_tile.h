@@ -39,10 +39,18 @@ namespace pla {
 #ifndef PLA_TILE_ABLATE
 #define PLA_TILE_ABLATE 0  // timing experiments (tools/build_alt.sh): 1 no selection, 2 no sample / threshold, 4 sweep = loads + min only, 8 no list appends, 16 no exponentials
 #endif
-constexpr int kTileWaves = 8;
+#ifndef PLA_TILE_WAVES
+#define PLA_TILE_WAVES 8   // waves that sweep (8 of them also search the thresholds and select)
+#endif
+constexpr int kTileWaves = PLA_TILE_WAVES;
+constexpr int kTileSelWaves = 8;
 constexpr int kTileThreads = kWave * kTileWaves;
-constexpr int kTileSample = 512;
+constexpr int kTileSample = 64 * kTileWaves;  // sampled draws per observation: 16 per lane
 constexpr int kTileCap = PLA_TILE_CAP;
+#ifndef PLA_TILE_CAP_STREAM
+#define PLA_TILE_CAP_STREAM 520   // ... in the streamed pass, where the fit kernel's workgroup needs 39.5 KB of the CU's LDS
+#endif
+constexpr int kTileCapStream = PLA_TILE_CAP_STREAM;
 
 struct TileParams {
   const void* in;      // element (observation i, draw s) at in[s * ld + i]
@@ -52,22 +60,34 @@ struct TileParams {
   int ks;              // the threshold leaves at most ks of the 512 sampled draws at or above it
 };
 
-template <typename T>
+// LDS of one workgroup.  What only the sweep needs (the dump counters and slots of the lanes without a candidate, the per-wave
+// partial sums) lies in the selection's scratch, which is idle then: with the lists at 520 entries the workgroup takes
+// 119.6 KB, and a four-wave workgroup of the streamed fit kernel (39.5 KB, pla_fit.h) fits on the CU beside it.
+template <typename T, int CAP>
 struct TileSmem {
   static constexpr int kObs = 128 / (int)sizeof(T);  // observations per group: one 128-byte piece of a draw
+  static constexpr int kCap = CAP;
   using Sel = ColSmem<CapsSmall>;
+  struct Sweep {
+    unsigned dumpc[kTileThreads];         // where the lanes whose draw is no candidate count (from 2^31 up: "past the end of any list")
+    T dumpv[kTileThreads];                // ... and store
+    double red[kTileWaves][kObs][4];      // C -> D: per wave and observation: min ll, max ll, sum e^x', sum e^-x'
+  };
   double tab[2 * kTabN];
   union {
-    T list[kObs][kTileCap];               // C, D: the candidates' stored log-likelihoods
+    T list[kObs][CAP];                    // C, D: the candidates' stored log-likelihoods
     float keys[kObs][kTileSample + 1];    // A, B: the sample, raw = -ll rounded up to f32 (+1: the rows start in different banks)
   };
-  Sel sel[kTileWaves];                    // D: scratch of one selection per wave
-  double red[kTileWaves][kObs][4];        // C -> D: per wave and observation: min ll, max ll, sum e^x', sum e^-x'
   double scal[kObs][2];                   // B -> C, D: provisional shift, threshold (both raw)
   unsigned cnt[kObs];                     // candidates seen (not capped)
-  unsigned dumpc[kTileThreads];           // where the lanes whose draw is no candidate count (from 2^31 up: "past the end of any list")
-  T dumpv[kTileThreads];                  // ... and store
+  unsigned again;                         // D: observations of the group whose list came out too short or too long (bit per observation)
+  unsigned pad_[3];
+  union {
+    Sel sel[kTileSelWaves];               // B (histograms of the threshold search), D: scratch of one selection per selecting wave
+    Sweep sweep;                          // C, and read at the very start of D
+  };
 };
+static_assert(sizeof(typename TileSmem<double, 640>::Sweep) <= sizeof(ColSmem<CapsSmall>) * kTileSelWaves, "the sweep's scratch lies inside the selection's");
 
 template <typename T>
 struct CandInTile {  // x = raw - max raw with the reference's single rounding (psis.py:134); the list holds ll = -raw
@@ -79,20 +99,29 @@ struct CandInTile {  // x = raw - max raw with the reference's single rounding (
   __device__ __forceinline__ double* dump_slot(int lane) const { return &sm.dump_slot[lane]; }
 };
 
-template <typename T>
+// SYNC: the streamed pass -- the fit kernel runs beside this one and takes each group (= one chunk of kQueueChunk observations)
+// as soon as its flag is up: agent-scope whole-line hand-over stores, F.done[group] set once every wave's stores have drained
+// (the protocol of the streamed wave kernel, pla_wave.h / pla_fit.h).
+template <typename T, bool SYNC>
 __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P, FastParams F, int tail_count) {
   static_assert(sizeof(T) == 8, "lane mapping and list size are laid out for 8-byte draws");
-  using SMT = TileSmem<T>;
+  using SMT = TileSmem<T, SYNC ? kTileCapStream : kTileCap>;
+  constexpr int kCap = SMT::kCap;
+  static_assert(!SYNC || SMT::kObs == kQueueChunk, "a group is a chunk of the streamed fit");
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
   SMT& sm = *reinterpret_cast<SMT*>(tile_lds);
   constexpr int kObs = SMT::kObs;                   // 16
   constexpr int kSub = kWave / kObs;                // draws per wave load: 4
   constexpr int kStep = kSub * kTileWaves;          // draws per step of the workgroup: 32
   constexpr int kPer = kTileSample / kStep;         // sampled draws per lane: 16
-  constexpr int kSelPer = kObs / kTileWaves;        // observations a wave selects for: 2
+  constexpr int kSelPer = kObs / kTileSelWaves;     // observations a selecting wave takes: 2
   const int tid = (int)threadIdx.x;
   for (int j = tid; j < kTabN; j += kTileThreads) exp_table_entry(sm.tab, j);
-  sm.dumpc[tid] = 0x80000000u;
+  if constexpr (SYNC) {
+    if (F.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (F.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (F.prio == 3) __builtin_amdgcn_s_setprio(3);
+  }
   __syncthreads();
   const int w = __builtin_amdgcn_readfirstlane(tid / kWave);
   const int lane = wave_lane();
@@ -106,34 +135,63 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
   const char* tabc = reinterpret_cast<const char*>(sm.tab);
 
   // ---- D. selection of group gp on its lists in LDS: wave w takes the observations kSelPer w + q -----------------------------
-  const auto select_group = [&](const int64_t gp) {
+  // `only`: the observations to select for (bit per observation).  `first_try`: an observation whose list came out too short or
+  // too long is not handed to the general kernel (which walks this layout at ~1 us per observation, 64 bytes of traffic per
+  // draw) but comes round again: its threshold is corrected from the exact count the sweep has just made -- an exponential
+  // tail through (threshold, count) and (row maximum, 1), as the long-row kernel's second attempts do (pla_chunked.h) -- and the
+  // group is swept once more for it alone.  Returns the observations that want that (0 when first_try is false).
+  const auto select_group = [&](const int64_t gp, const unsigned only, const bool first_try) -> unsigned {
     const int64_t obs0 = gp * kObs;
-#pragma unroll 1
+    if (tid == 0) sm.again = 0u;
+    // the sweep's per-wave partial results first, for all of this wave's observations: they lie in the selection's scratch,
+    // which the barrier below releases (every lane reads the same entries: broadcasts, and one order of summation)
+    double pm[kSelPer], pmn[kSelPer], ps1[kSelPer], ps2[kSelPer];
+    if (w < kTileSelWaves) {
+#pragma unroll
+      for (int q = 0; q < kSelPer; ++q) {
+        const int oo = w * kSelPer + q;
+        double lmin = INF, lmax = -INF, s1p = 0.0, s2p = 0.0;
+#pragma unroll
+        for (int k = 0; k < kTileWaves; ++k) {
+          const double* rd = sm.sweep.red[k][oo];
+          lmin = fmin(lmin, rd[0]);
+          lmax = fmax(lmax, rd[1]);
+          s1p += rd[2];
+          s2p += rd[3];
+        }
+        pm[q] = -lmin; pmn[q] = -lmax; ps1[q] = s1p; ps2[q] = s2p;
+      }
+    }
+    __syncthreads();
+#pragma unroll
     for (int q = 0; q < kSelPer; ++q) {
+      if (w >= kTileSelWaves) break;
       const int oo = w * kSelPer + q;
       const int64_t r = obs0 + oo;
       if (r >= P.n_obs) break;  // (wave-uniform)
+      if (!((only >> oo) & 1u)) continue;
       if constexpr ((PLA_TILE_ABLATE & 1) != 0) {
-        if (lane == 0) F.ws_s[r * F.ws_sstride + 5] = sm.red[0][oo][0] + sm.red[0][oo][2] + (double)sm.cnt[oo];
+        if (lane == 0) F.ws_s[r * F.ws_sstride + 5] = pm[q] + ps1[q] + (double)sm.cnt[oo];
         continue;
       }
-      double lmin = INF, lmax = -INF, s1p = 0.0, s2p = 0.0;
-#pragma unroll
-      for (int k = 0; k < kTileWaves; ++k) {  // (every lane reads the same eight entries: broadcasts, and one order of summation)
-        const double* rd = sm.red[k][oo];
-        lmin = fmin(lmin, rd[0]);
-        lmax = fmax(lmax, rd[1]);
-        s1p += rd[2];
-        s2p += rd[3];
-      }
-      const double m = uniform_d(-lmin), mn = uniform_d(-lmax);
-      s1p = uniform_d(s1p);
-      s2p = uniform_d(s2p);
+      const double m = uniform_d(pm[q]), mn = uniform_d(pmn[q]);
+      const double s1p = uniform_d(ps1[q]), s2p = uniform_d(ps2[q]);
       const double mp = uniform_d(sm.scal[oo][0]), t_raw = uniform_d(sm.scal[oo][1]);
       const int ncand = __builtin_amdgcn_readfirstlane((int)sm.cnt[oo]);
       const double R = m - mn, delta = m - mp;  // (delta: the row's maximum against the sample's, rounded up to f32)
-      bool slow = !(R < kWaveMaxRange) || ncand < M + 1 || ncand > kTileCap || !(fabs(s1p) < INF) || !(fabs(s2p) < INF) ||
-                  !(fabs(delta) < kWaveMaxRange);
+      const bool bad_row = !(R < kWaveMaxRange) || !(fabs(s1p) < INF) || !(fabs(s2p) < INF) || !(fabs(delta) < kWaveMaxRange);
+      const bool bad_count = ncand < M + 1 || ncand > kCap;
+      if (first_try && bad_count && !bad_row && ncand >= 2 && m > t_raw) {
+        // count(x) ~ e^(-lambda (max - x)) through (t_raw, ncand) and (m, 1): the threshold with the middle of the list's
+        // range above it
+        const float ratio = __logf(0.5f * (float)(M + 1 + kCap)) / __logf((float)ncand);
+        if (lane == 0) {
+          sm.scal[oo][1] = m - (m - t_raw) * (double)ratio;
+          atomicOr(&sm.again, 1u << oo);
+        }
+        continue;
+      }
+      bool slow = bad_row || bad_count;
       typename SMT::Sel& ss = sm.sel[w];
       if (!slow) {
         wave_sync();  // the previous observation is done with the scratch
@@ -152,25 +210,38 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
         const double s2 = lane == 0 ? s2p * exp_tab(delta, sm.tab) : 0.0;
         const CandInTile<T> src{sm.list[oo], m, ss};
         wave_sync();
-        wave_select_split<typename SMT::Sel, SMT, (CapsSmall::kMaxTail + 63) / 64, CandInTile<T>>(
+        wave_select_split<typename SMT::Sel, SMT, (CapsSmall::kMaxTail + 63) / 64, CandInTile<T>, SYNC>(
             F, ss, sm, r, lane, M, m, mn, s1, s2, (unsigned)ncand, k1, sh, magic, c256, slow, src);
       }
       // (a scalar branch: the wait for the counter's old value must not lie on the path of the observations that stay -- it
       // would also wait for the next group's loads, which are in flight through this selection)
       if (__builtin_amdgcn_readfirstlane((int)slow) != 0 && PLA_TILE_ABLATE == 0) {
+        // (tail length -1: on the list for the general kernel, nothing for the fit kernel)
+        ws_store_scalars<SYNC>(F, r, lane, 0.0, 0.0, 0.0, 0.0, 0.0, -1.0);
         if (lane == 0) {
           const unsigned long long idx = atomicAdd(&F.counters[0], 1ull);
           F.slow_list[idx] = (unsigned)r + F.slow_base;
-          F.ws_s[r * F.ws_sstride + 5] = -1.0;  // tail length -1: on the list, nothing for the fit kernel
         }
       }
     }
+    // the lists and the scratch are free for the next group from here on; streamed pass: every hand-over store of the group
+    // has drained (each wave waits for its own, then the barrier), and the fit kernel may have the group
+    if constexpr (SYNC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned again = (unsigned)__builtin_amdgcn_readfirstlane((int)sm.again);
+    if constexpr (SYNC) {  // (a group that is swept again is the fit kernel's when that is over)
+      if (tid == 0 && again == 0u) __hip_atomic_store(&F.done[gp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return again;
   };
   const auto sample_step = [&](int j) { return (int)(((int64_t)(kTileWaves * j + w) * nit) / (kTileWaves * kPer)); };
   // One trip of the loop: the sample loads of group g are ISSUED, the selection of the group before it runs on the lists in LDS
   // while they fly, then the sample is turned into thresholds and the group is swept.  (One place of issue for the sample; the
   // loop is entered with no group behind and left with none ahead.)
-  int64_t g = blockIdx.x, prev = -1;
+  int64_t g = blockIdx.x, prev = -1, resume = -1;
+  unsigned prev_only = 0xffffu;  // the observations of `prev` to select for
+  bool prev_first = true;        // ... for the first time
+  unsigned redo = 0u;            // non-zero: group g is swept a second time, for these observations
   for (;;) {
     const bool have = g < ngroups;
     const int64_t obs0 = g * kObs;
@@ -201,10 +272,24 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
 #pragma unroll
       for (int u = 0; u < R; ++u) ring[u] = load_step(u < last ? u : last);
     }
-    if (prev >= 0) select_group(prev);
+    if (prev >= 0) {  // (ends on a barrier: the lists of the group before are free for this group's sample)
+      const unsigned again = select_group(prev, prev_only, prev_first);
+      if (again != 0u) {  // once more through `prev` (the loads just issued are dropped: a few groups in a hundred)
+        resume = g;
+        g = prev;
+        prev = -1;
+        redo = again;
+        continue;
+      }
+    }
     if (!have) break;
-    __syncthreads();  // the lists of the group before are free for this group's sample
-    if constexpr (!(PLA_TILE_ABLATE & 2)) {
+    if (redo != 0u) {
+      // second sweep of a group: the corrected thresholds are in place, everybody else's is out of reach
+      if (tid < kObs) {
+        if (!((redo >> tid) & 1u)) sm.scal[tid][1] = INF;
+        sm.cnt[tid] = 0u;
+      }
+    } else if constexpr (!(PLA_TILE_ABLATE & 2)) {
 #pragma unroll
       for (int j = 0; j < kPer; ++j)  // rounded up: the threshold may only err towards FEWER candidates by what one float ulp is worth
         sm.keys[o][(w * kSub + dsub) * kPer + j] = __double2float_ru(-(double)sv[j]);
@@ -215,6 +300,7 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
       // same again inside that bin.  (Bisection on ballot counts, 12 halvings x 8 compares per observation, was a fifth of
       // the instructions of the whole sweep.)  The threshold is the lower edge of the final sub-bin: ks .. ks + (members of
       // that sub-bin) - 1 of the sample lie at or above it.
+      if (w < kTileSelWaves) {
       constexpr int KX = kTileSample / kWave;
       float kx[kSelPer][KX], hi[kSelPer];
       double hmax[kSelPer];
@@ -302,6 +388,7 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
           sm.cnt[w * kSelPer + q] = 0u;
         }
       }
+      }
     } else if (tid < kObs) {
       sm.scal[tid][0] = 0.0;
       sm.scal[tid][1] = 1e300;
@@ -314,8 +401,9 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
     double nmn = INF, nmx = -INF, s1 = 0.0, s2 = 0.0;  // min / max of ll = -(max / min of raw)
     T* const mylist = sm.list[o];
     unsigned* const mycnt = &sm.cnt[o];
-    unsigned* const mydumpc = &sm.dumpc[tid];
-    T* const mydumpv = &sm.dumpv[tid];
+    unsigned* const mydumpc = &sm.sweep.dumpc[tid];
+    *mydumpc = 0x80000000u;  // (this thread's own word, in scratch the threshold search and the selection have used since)
+    T* const mydumpv = &sm.sweep.dumpv[tid];
     // the constants of the sweep live in registers for its whole length (MachineLICM is off for this library: the compiler
     // would otherwise re-materialise each of them with s_mov per use -- ten scalar instructions per draw)
     int c4096 = 4096, cm4096 = -4096, four = 4;
@@ -363,7 +451,7 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
       if constexpr ((PLA_TILE_ABLATE & 4) != 0) return;
       if constexpr ((PLA_TILE_ABLATE & 16) != 0) {
         s1 += px[sl];
-        if constexpr (!(PLA_TILE_ABLATE & 8)) *(ppos[sl] < (unsigned)kTileCap ? &mylist[ppos[sl]] : mydumpv) = (T)pll[sl];
+        if constexpr (!(PLA_TILE_ABLATE & 8)) *(ppos[sl] < (unsigned)kCap ? &mylist[ppos[sl]] : mydumpv) = (T)pll[sl];
         return;
       }
       const double x = px[sl], t = pt[sl];
@@ -376,11 +464,11 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
       s2 = fma(__hiloint2double(mad_i24(k, cm4096, ptt[sl].w), ptt[sl].z), fma(-rr, O, E), s2);
       if constexpr (!(PLA_TILE_ABLATE & 8)) {
         if constexpr (PLA_TILE_MASKED != 0) {
-          if (ppos[sl] < (unsigned)kTileCap) mylist[ppos[sl]] = (T)pll[sl];
+          if (ppos[sl] < (unsigned)kCap) mylist[ppos[sl]] = (T)pll[sl];
         } else if constexpr ((PLA_TILE_ABLATE & 32) != 0) {
-          nmx = vmax_nc<false>(nmx, ppos[sl] < (unsigned)kTileCap ? 1.0 : 2.0);
+          nmx = vmax_nc<false>(nmx, ppos[sl] < (unsigned)kCap ? 1.0 : 2.0);
         } else {
-          *(ppos[sl] < (unsigned)kTileCap ? &mylist[ppos[sl]] : mydumpv) = (T)pll[sl];
+          *(ppos[sl] < (unsigned)kCap ? &mylist[ppos[sl]] : mydumpv) = (T)pll[sl];
         }
       }
     };
@@ -443,12 +531,15 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
       s2 += __shfl_xor(s2, off);
     }
     if (dsub == 0) {
-      double* rd = sm.red[w][o];
+      double* rd = sm.sweep.red[w][o];
       rd[0] = nmn; rd[1] = nmx; rd[2] = s1; rd[3] = s2;
     }
     __syncthreads();
     prev = g;
-    g += gridDim.x;
+    prev_only = redo != 0u ? redo : 0xffffu;
+    prev_first = redo == 0u;
+    g = redo != 0u ? resume : g + (int64_t)gridDim.x;
+    redo = 0u;
   }
 }
 

@@ -779,8 +779,8 @@ def test_column_kernels_on_observation_fastest_matrices(eng):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,S,reff", [(300_011, 4000, 0.7), (100_003, 1000, 1.0), (50_001, 777, 1.0), (20_000, 4096, 0.7)])
-def test_tile_kernel_on_observation_fastest_f64_matrices(eng, N, S, reff):
+@pytest.mark.parametrize("N,S,reff", [(300_011, 4000, 1.0), (60_007, 4000, 0.7), (100_003, 1000, 1.0), (50_001, 777, 1.0), (20_000, 4096, 0.7)])
+def test_tile_kernel_on_observation_fastest_f64_matrices(eng, N, S, reff, monkeypatch):
     """pla_tile.h: a workgroup per 16 observations on an f64 (S, N) buffer -- a ragged last group, row lengths with steps behind
     the last whole batch and draws behind the last whole step, heavy-tailed rows, rows with non-finite draws and a constant row
     (general kernel through the strided view), against the draws-fastest pass and the oracle."""
@@ -797,14 +797,22 @@ def test_tile_kernel_on_observation_fastest_f64_matrices(eng, N, S, reff):
     assert view.stride(0) == 1
     a = eng.psis_loo(view, M, "psis", 1.0, 0.7)
     assert "tile_loo_kernel" in eng.last_kernels()
+    streamed = "fit_rows_stream_kernel" in eng.last_kernels()
+    # (the streamed pass has the shorter lists: tail counts of 227 and 230 at S ~ 4000 leave too little room around the expected count)
+    assert streamed == (reff == 1.0), eng.last_kernels()
+    monkeypatch.setenv("PLA_PIPE", "0")  # the two kernels back to back (longer lists, another threshold: the same tails)
+    a0 = eng.psis_loo(view, M, "psis", 1.0, 0.7)
+    assert "tile_loo_kernel" in eng.last_kernels() and "fit_rows_stream_kernel" not in eng.last_kernels()
+    monkeypatch.delenv("PLA_PIPE")
     b = eng.psis_loo(t, M, "psis", 1.0, 0.7)
     torch.cuda.synchronize()
-    for key in ("diag", "loo_i", "lppd_i"):
-        x, y = a[key].cpu().numpy(), b[key].cpu().numpy()
-        assert np.array_equal(np.isnan(x), np.isnan(y)) and np.array_equal(np.isinf(x), np.isinf(y)), key
-        ok = np.isfinite(y)
-        np.testing.assert_allclose(x[ok], y[ok], rtol=1e-10, atol=1e-11, err_msg=key)
-    assert a["agg"][7].item() <= 0.01 * N
+    for res in (a, a0):
+        for key in ("diag", "loo_i", "lppd_i"):
+            x, y = res[key].cpu().numpy(), b[key].cpu().numpy()
+            assert np.array_equal(np.isnan(x), np.isnan(y)) and np.array_equal(np.isinf(x), np.isinf(y)), key
+            ok = np.isfinite(y)
+            np.testing.assert_allclose(x[ok], y[ok], rtol=1e-10, atol=1e-11, err_msg=key)
+        assert res["agg"][7].item() <= 0.01 * N
     a2 = eng.psis_loo(view, M, "psis", 1.0, 0.7)  # (lists are appended to in whatever order the waves arrive: the results may not depend on it)
     for key in ("diag", "loo_i", "lppd_i", "agg"):
         assert torch.equal(a[key], a2[key]) or np.array_equal(a[key].cpu().numpy(), a2[key].cpu().numpy(), equal_nan=True), key

@@ -13,7 +13,7 @@ import csv, glob
 for f in glob.glob("$OUT/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Name"].split("(")[0]
-        if "tile_" in n:
+        if any(k in n for k in ("tile_", "fit_rows", "slow_rows", "reduce", "wave_loo")):
             print("%-10s %-40s calls %3s  avg %9.3f us" % ("$NAME", n[:40], r["Calls"], float(r["AverageNs"]) / 1e3), flush=True)
 PY
 done
