@@ -88,6 +88,9 @@ struct TileSmem {
   };
 };
 static_assert(sizeof(typename TileSmem<double, 640>::Sweep) <= sizeof(ColSmem<CapsSmall>) * kTileSelWaves, "the sweep's scratch lies inside the selection's");
+// (the streamed fit kernel's four-wave workgroup: 9 744 bytes static + 30 720 of coefficient scratch at three 64-value blocks,
+// tests/test_kernel_resources.py holds it to these 40 960)
+static_assert(sizeof(TileSmem<double, kTileCapStream>) + 40960 <= 160 * 1024, "streamed pass: the fit kernel's workgroup must fit beside this one");
 
 template <typename T>
 struct CandInTile {  // x = raw - max raw with the reference's single rounding (psis.py:134); the list holds ll = -raw

@@ -52,11 +52,19 @@ SCRATCH_OK = {
 }
 
 
-@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
-def test_row_kernels_do_not_spill(tmp_path):
+@pytest.fixture(scope="module")
+def isa_lines(tmp_path_factory):
+    """The generated code of the kernel file, compiled ONCE for the tests of this module (100 s per compile)."""
     import isa_stats
 
-    lines = isa_stats.compile_isa(out=str(tmp_path / "kernels.s"))
+    return isa_stats.compile_isa(out=str(tmp_path_factory.mktemp("isa") / "kernels.s"))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+def test_row_kernels_do_not_spill(isa_lines):
+    import isa_stats
+
+    lines = isa_lines
     for pat, lds_limit in KERNELS.items():
         name, total, _, res = isa_stats.kernel_stats(lines, pat)
         assert res.get("ScratchSize", 0) == 0, (name, res)
@@ -72,12 +80,12 @@ def test_row_kernels_do_not_spill(tmp_path):
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
-def test_streamed_pass_kernels_fit_on_one_cu_together(tmp_path):
+def test_streamed_pass_kernels_fit_on_one_cu_together(isa_lines):
     """The streamed split pass needs two workgroups of the wave kernel AND one four-wave workgroup of the fit kernel resident on
     every CU at once: 512 vector registers per SIMD (allocated in eights) and 160 KB of LDS are the budget."""
     import isa_stats
 
-    lines = isa_stats.compile_isa(out=str(tmp_path / "kernels.s"))
+    lines = isa_lines
     _, _, _, wave = isa_stats.kernel_stats(lines, "wave_loo_kernelIdLi2ELb0ENS_9CapsSmallELb1ELb1")
     name, total, _, fit = isa_stats.kernel_stats(lines, "fit_rows_stream_kernelILi3")
     assert fit.get("ScratchSize", 0) == 0 and not any(k.startswith("scratch_") for k in total), (name, fit)
@@ -86,3 +94,23 @@ def test_streamed_pass_kernels_fit_on_one_cu_together(tmp_path):
     assert 2 * alloc(vw) + alloc(vf) <= 512, (vw, vf)
     coef = 4 * 5 * 4 * 48 * 8  # dynamic LDS of the fit kernel at three 64-value blocks (fit_coef_bytes<3, 4>)
     assert 2 * wave["LDSByteSize"] + fit["LDSByteSize"] + coef <= 160 * 1024, (wave["LDSByteSize"], fit["LDSByteSize"])
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+def test_streamed_tile_pass_kernels_fit_on_one_cu_together(isa_lines):
+    """Observations-fastest streamed pass (pla_tile.h): ONE eight-wave workgroup of the tile kernel (two waves per SIMD) and one
+    four-wave workgroup of the fit kernel per CU.  Registers: 2 x tile + 1 x fit <= 512 per SIMD; LDS: the tile kernel's is
+    dynamic (a static_assert in pla_tile.h holds it to 160 KB - 40 960), the fit kernel's must stay within those 40 960."""
+    import isa_stats
+
+    lines = isa_lines
+    alloc = lambda v: (v + 7) // 8 * 8  # noqa: E731
+    name, total, _, fit = isa_stats.kernel_stats(lines, "fit_rows_stream_kernelILi3")
+    coef = 4 * 5 * 4 * 48 * 8
+    assert fit["LDSByteSize"] + coef <= 40960, fit
+    for pat in ("tile_loo_kernelIdLb1", "tile_loo_kernelIdLb0"):
+        tname, ttotal, _, tile = isa_stats.kernel_stats(lines, pat)
+        assert tile.get("ScratchSize", 0) == 0 and not any(k.startswith("scratch_") for k in ttotal), (tname, tile)
+        assert tile["NumVgprs"] + tile.get("NumAgprs", 0) <= 256, (tname, tile)
+    _, _, _, tile = isa_stats.kernel_stats(lines, "tile_loo_kernelIdLb1")
+    assert 2 * alloc(tile["NumVgprs"] + tile.get("NumAgprs", 0)) + alloc(fit["NumVgprs"] + fit.get("NumAgprs", 0)) <= 512, (tile, fit)
