@@ -191,6 +191,9 @@ __global__ __launch_bounds__(BLOCK) void waic_rows_kernel(WaicParams P) {
 //     (n, mean, M2) with the pairwise update of Chan, Golub & LeVeque -- as accurate as np.var's two passes over the row.
 // No transposing pass through HBM (19.7 ms for C3 in round 1): the matrix is read once.
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef PLA_WAIC_COL_BATCHES
+#define PLA_WAIC_COL_BATCHES 3
+#endif
 template <typename T>
 __global__ __launch_bounds__(256) void waic_col_kernel(WaicParams P, int64_t ld) {
   __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];
@@ -235,21 +238,42 @@ __global__ __launch_bounds__(256) void waic_col_kernel(WaicParams P, int64_t ld)
     m2 += qb + delta * delta * ((double)n_before * (double)nb / tot);
     mean += delta * ((double)nb / tot);
   };
-  int s = 0;
-#pragma unroll 1
-  for (; s < S; s += U) {
-    const int nb = S - s < U ? S - s : U;  // (wave-uniform)
-    T v[U];
+  // NB batches of U draws per lane in flight: the loads of batch b + NB are issued into the registers of batch b as soon as
+  // that batch has been converted, before its arithmetic (one batch, loaded and then computed on, left the kernel at 4.5 TB/s
+  // on occupancy alone; tools/microbench/col_stream.hip: this access shape streams at 6.5)
+  constexpr int NB = PLA_WAIC_COL_BATCHES;
+  T ring[NB][U];
+  const auto fetch = [&](T (&dst)[U], const int s0) {  // (draws past the row: its last draw again, never looked at)
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(col + (int64_t)(s + (u < nb ? u : 0)) * ld);
+    for (int u = 0; u < U; ++u) {
+      const int d = s0 + u < S ? s0 + u : S - 1;
+      dst[u] = __builtin_nontemporal_load(col + (int64_t)d * ld);
+    }
+  };
+#pragma unroll
+  for (int b = 0; b < NB; ++b) fetch(ring[b], b * U);
+  const auto take = [&](const int b, const int s0, const int nb) {
     double x[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       unsigned rep = 0;
-      x[u] = (double)waic_sanitize(v[u], rep);  // waic.py:112-135
+      x[u] = (double)waic_sanitize(ring[b][u], rep);  // waic.py:112-135
       nrep += (u < nb && live) ? rep : 0u;
     }
-    batch(x, s, nb);
+    fetch(ring[b], s0 + NB * U);
+    batch(x, s0, nb);
+  };
+  int s = 0;
+#pragma unroll 1
+  for (; s + NB * U <= S; s += NB * U) {  // whole rounds: no control flow between the batches (the load counters stay exact)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) take(b, s + b * U, U);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {  // what is left of the row (already in the ring)
+    const int s0 = s + b * U;
+    const int nb = S - s0 < U ? S - s0 : U;  // (wave-uniform)
+    if (nb > 0) take(b, s0, nb);
   }
   if (live) {
     const double var = m2 / (double)S;

@@ -29,7 +29,8 @@ t_of, r1 = timed(lambda: eng.psis_loo(view, 190, "psis", 1.0, 0.7, pointwise=Fal
 t_wa, _ = timed(lambda: eng.waic(view, 1.0, pointwise=False))
 del a
 t_torch, _ = timed(lambda: view.contiguous(), 2)
-path = "transposing ingestion" if os.environ.get("PLA_INGEST_TRANSPOSE", "0") not in ("", "0") else "lane-per-observation kernels"
+eng.psis_loo(view, 190, "psis", 1.0, 0.7, pointwise=False)
+path = "transposing ingestion" if os.environ.get("PLA_INGEST_TRANSPOSE", "0") not in ("", "0") else eng.last_kernels()
 rel = abs(r0["agg"][1].item() - r1["agg"][1].item()) / abs(r0["agg"][1].item())
 print(json.dumps({"workload": f"f64 S={S} x N={N}, device-resident", "obs_fastest_loo_path": path, "loo_draws_fastest_ms": t_rm,
                   "loo_obs_fastest_ms": t_of, "obs_fastest_tb_per_s_algorithmic": N * (S * 8 + 24) / (t_of * 1e-3) / 1e12,
