@@ -110,6 +110,31 @@ def test_order_of_the_draws(eng, kind, S, dt, bound):
     assert frac <= bound, f"{kind} S={S}: {res['agg'][7]:.0f} of {n} rows left the fast selection path"
 
 
+@pytest.mark.parametrize("kind,S", [("iid", 4000), ("ascending", 4000), ("descending", 4000), ("ar1", 4000), ("chains_ar1", 4000),
+                                    ("chains_scale", 4000), ("chains_ar1", 2000)])
+def test_order_of_the_draws_observations_fastest(eng, kind, S):
+    """The same orders of draws on a device matrix with the observations fastest (pla_tile.h): its threshold comes from 512 draws
+    in 128 clusters spread over the row, and an observation whose list comes out too short or too long is swept a second time
+    with a threshold corrected from the exact count -- the general kernel (1 us per observation in this layout) sees next to nothing."""
+    import torch
+
+    n = 3000
+    rng = np.random.default_rng(zlib.crc32(f"{kind}{S}".encode()))
+    ll = make_rows(kind, n, S, rng)
+    M = orc.tail_count(S, 1.0)
+    view = torch.from_numpy(np.ascontiguousarray(ll.T)).cuda().T
+    assert view.stride(0) == 1
+    res = eng.psis_loo(view, M, "psis", 1.0, 0.7)
+    assert "tile_loo_kernel" in eng.last_kernels()
+    frac = res["agg"][7].item() / n
+    idx = np.arange(0, n, 15)
+    ref = orc.loo_arrays(ll[idx], 1.0)
+    close(res["diag"].cpu().numpy()[idx], ref["khat"], what="khat")
+    close(res["loo_i"].cpu().numpy()[idx], ref["loo_i"], what="loo_i")
+    close(res["lppd_i"].cpu().numpy()[idx], ref["lppd_i"], what="lppd_i")
+    assert frac <= 0.004, f"{kind} S={S}: {res['agg'][7].item():.0f} of {n} rows left the fast selection path"
+
+
 def test_chain_major_weights(eng):
     """Same for the weights flavour (psislw): chain-major autocorrelated rows, smoothed log-weights against the oracle."""
     rng = np.random.default_rng(5)
