@@ -25,4 +25,10 @@ timeout -k 10 200 python tools/bench_is.py --method sis 2>/dev/null > $F/${TAG}_
 timeout -k 10 200 python tools/bench_waic.py 2>/dev/null > $F/${TAG}_bench_waic.json
 timeout -k 10 200 python tools/bench_e_loo.py 2>/dev/null > $F/${TAG}_bench_e_loo.json
 timeout -k 10 200 python tools/obs_fastest_cost.py 2>/dev/null > $F/${TAG}_bench_obs_fastest.json
+timeout -k 10 200 python tools/tile_time.py 2>/dev/null | tail -1 > $F/${TAG}_bench_obs_fastest_tile_streamed.json
+PLA_PIPE=0 timeout -k 10 200 python tools/tile_time.py 2>/dev/null | tail -1 > $F/${TAG}_bench_obs_fastest_tile_back_to_back.json
+PLA_NO_TILE=1 timeout -k 10 200 python tools/tile_time.py 2>/dev/null | tail -1 > $F/${TAG}_bench_obs_fastest_lane_per_observation.json
+timeout -k 10 200 python tools/waic_col_time.py 2>/dev/null | tail -1 > $F/${TAG}_bench_waic_obs_fastest.json
+bash tools/ktrace_tile_timeline.sh 2>&1 | grep -v "^W2026" > $F/${TAG}_tile_kernel_timeline.txt; echo "tile timeline done"
+OBS=262144 timeout -k 10 600 bash tools/pmc_col.sh > $F/${TAG}_col_traffic.txt 2>&1; echo "tile traffic done"
 for f in $F/${TAG}_bench*.json; do echo "== $f"; cut -c1-420 $f; done
