@@ -153,6 +153,32 @@ def test_streamed_pass_full_block_at_the_widest_hand_over(eng, monkeypatch):
     torch.cuda.empty_cache()
 
 
+def test_observations_fastest_more_than_one_block(eng):
+    """The tile kernel of the observations-fastest path (pla_tile.h) runs in blocks of 2^20 observations, streamed: flags, work
+    counter and hand-over buffer are reused from block to block, the second block starts in the middle of the matrix's rows.
+    2^20 + 16 * 37 + 5 observations (a ragged last group) against the draws-fastest pass, every observation."""
+    import torch
+
+    S, n = 4000, (1 << 20) + 16 * 37 + 5
+    M = orc.tail_count(S, 1.0)
+    t = torch.empty((n, S), dtype=torch.float64, device="cuda")
+    eng.fill_synthetic(t, seed=0x5EED000B)
+    b = eng.psis_loo(t, M, "psis", 1.0, 0.7)
+    ref = {k: b[k].clone() for k in ("diag", "loo_i", "lppd_i", "agg")}
+    view = t.T.contiguous().T
+    del t
+    torch.cuda.empty_cache()
+    a = eng.psis_loo(view, M, "psis", 1.0, 0.7)
+    assert "tile_loo_kernel<SYNC>" in eng.last_kernels()
+    torch.cuda.synchronize()
+    for k in ("diag", "loo_i", "lppd_i"):
+        assert torch.allclose(a[k], ref[k], rtol=1e-10, atol=1e-11), k
+    assert abs(a["agg"][1].item() - ref["agg"][1].item()) <= 1e-10 * abs(ref["agg"][1].item())
+    assert a["agg"][7].item() <= 1e-4 * n
+    del view
+    torch.cuda.empty_cache()
+
+
 def test_c5_shard(eng):
     """One GPU's shard of C5: S=20 000 x N=125 000 f32 (10 GB), seed 0x5EED0005, rows with i mod 10 in {0, 3, 6} drawn
     with k in [1, 1.3): ~30 % of the observations end above khat = 0.7.  500 rows against the oracle on the upcast data."""
