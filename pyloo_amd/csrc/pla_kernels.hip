@@ -11,6 +11,7 @@
 //   6. log-sum-exp normaliser, loo_i and lppd_i                       (psis.py:158, loo.py:289-337)
 // The weight matrix is never materialised in LOO mode: for draws outside the tail
 // lw_s + ll_s == -max - LSE exactly in real arithmetic, so only the <= M tail terms need an exp.
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdarg>
@@ -804,12 +805,22 @@ bool tile_supported(int dtype, int n_draws, int tail_count, int64_t ld, bool str
   return true;
 }
 
+// (the kernel's LDS is beyond the 64 KB a launch may ask for by default; the attribute belongs to the device's copy of the
+// function, so it is set once per device of the process -- callers hold the engine's mutex, engines of different devices may
+// race for their own slot only)
 template <bool SYNC>
 static bool tile_lds_attr() {
   using SMT = TileSmem<double, SYNC ? kTileCapStream : kTileCap>;
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_loo_kernel<double, SYNC>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SMT)) == hipSuccess;
-  return ok;
+  static std::atomic<int> state[64];  // per device: 0 not tried, 1 set, 2 refused
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  int st = state[dev].load(std::memory_order_acquire);
+  if (st == 0) {
+    st = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_loo_kernel<double, SYNC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)sizeof(SMT)) == hipSuccess ? 1 : 2;
+    state[dev].store(st, std::memory_order_release);
+  }
+  return st == 1;
 }
 
 hipError_t launch_tile(const RowsParams& p, int dtype, int ks, hipStream_t stream, const PipeStreams* pipe) {

@@ -26,7 +26,8 @@ def compile_isa(extra=(), out="/tmp/pla_isa.s"):
 def kernel_stats(lines, pat):
     """Instruction mix, per-phase mix and resource lines of the first kernel whose mangled name contains `pat`."""
     start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + re.escape(pat) + r"\w*:", l))
-    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+    # (the end of the function, not its first s_endpgm: a kernel may leave early and go on for a thousand lines)
+    end = next(i for i in range(start, len(lines)) if re.match(r"^\.Lfunc_end\d+:", lines[i]))
     total = collections.Counter()
     phases = collections.defaultdict(collections.Counter)
     ph = 0
