@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0003)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--layout", default="draws", choices=["draws", "obs"],
+                    help="which index of the matrix is contiguous: the draws of an observation (default, BASELINE's C3) or the "
+                         "observations of a draw -- ArviZ's (chain, draw, *obs) as pl.loo(idata) stacks it (loo.py:189), read in place")
     ap.add_argument("--rows", default="iid", choices=["iid", "chain_ar1"],
                     help="iid: BASELINE's generator (exchangeable draws).  chain_ar1: the same marginals as MCMC delivers them -- "
                          "4 chains stacked chain-major, AR(1) with rho = 0.9 in the draw index, per-chain offsets (not a BASELINE "
@@ -173,6 +176,10 @@ def main():
         label += " rows as chain-major AR(1) chains (rho 0.9, 4 chains, per-chain offsets sd 0.1)"
     else:
         eng.fill_synthetic(ll, seed=args.seed, row0=rank * n_local, k_lo=0.05, k_hi=k_hi, heavy_lo=heavy[0], heavy_hi=heavy[1])
+    if args.layout == "obs":
+        ll = ll.t().contiguous().t()  # an (n_obs, n_draws) view of an (n_draws, n_obs) buffer: the same numbers, observations fastest
+        assert ll.stride(0) == 1
+        label += "; observations fastest in memory (the (obs, sample) view of ArviZ's (chain, draw, obs) storage)"
     torch.cuda.synchronize()
 
     reff = 1.0
@@ -237,6 +244,8 @@ def main():
         return
 
     traffic, traffic_file = measured_traffic(n_local, S, args.dtype)
+    if args.layout == "obs":  # (the committed counts are of the draws-fastest pass; this layout's: profiles/r03_col_traffic.txt, per block)
+        traffic, traffic_file = None, None
     out = {
         "metric": "psis_loo_observations_per_second",
         "value": world * n_local * args.steps / elapsed,

@@ -624,6 +624,11 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
         if (tile_stream) {
           pla::PipeStreams ps{eng->pipe_first, eng->pipe_second, eng->pipe_fork, eng->pipe_join1, eng->pipe_join2, (unsigned*)eng->d_sync,
                               nullptr, nullptr, r0 == 0};
+          if (eng->timing && eng->pipe_timed < pla_engine::kPipeTimed) {
+            ps.before_first = eng->pipe_t0[eng->pipe_timed];
+            ps.after_first = eng->pipe_t1[eng->pipe_timed];
+            eng->pipe_timed += 1;
+          }
           PLA_HIP(pla::launch_tile(p, dtype, tile_ks, s, &ps));
           eng->last_kernels = "tile_loo_kernel<SYNC> (a workgroup per 16 observations, matrix read in place) with fit_rows_stream_kernel beside it "
                               "on a second stream + fit_rows_kernel (leftovers) + slow_rows_kernel";

@@ -18,6 +18,7 @@ timeout -k 10 300 python bench.py > $F/${TAG}_bench.json 2> $F/bench.err; echo "
 timeout -k 10 300 python bench.py --config C5 > $F/${TAG}_bench_c5.json 2> $F/bench_c5.err; echo "bench C5 rc=$?"
 timeout -k 10 300 python bench.py --rows chain_ar1 --no-cpu > $F/${TAG}_bench_chain_ar1.json 2>/dev/null; echo "bench chain_ar1 rc=$?"
 PLA_PIPE=0 timeout -k 10 300 python bench.py --no-cpu > $F/${TAG}_bench_back_to_back.json 2>/dev/null; echo "bench PLA_PIPE=0 rc=$?"
+timeout -k 10 300 python bench.py --layout obs --no-cpu > $F/${TAG}_bench_layout_obs.json 2>/dev/null; echo "bench --layout obs rc=$?"
 timeout -k 10 200 python tools/bench_weights.py 2>/dev/null > $F/${TAG}_bench_weights.json
 timeout -k 10 200 python tools/bench_weights.py --obs 60000 --draws 20000 --dtype f32 2>/dev/null > $F/${TAG}_bench_weights_s20000_f32.json
 timeout -k 10 200 python tools/bench_is.py --method tis 2>/dev/null > $F/${TAG}_bench_tis.json
