@@ -821,3 +821,27 @@ def test_tile_kernel_on_observation_fastest_f64_matrices(eng, N, S, reff, monkey
     close(a["diag"].cpu().numpy()[idx], ref["khat"], what="khat")
     close(a["loo_i"].cpu().numpy()[idx], ref["loo_i"], what="loo_i")
     close(a["lppd_i"].cpu().numpy()[idx], ref["lppd_i"], what="lppd_i")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S", [512, 513, 543, 767, 768, 769, 800, 1535, 1536, 2047, 3999, 4001, 4096, 5000])
+def test_tile_kernel_row_lengths_and_group_counts(eng, S):
+    """Row lengths around every boundary of the tile kernel's sweep (32 draws per step, rings of 24 steps, the remainders behind
+    both, rows shorter than one ring) times observation counts around its groups of 16 and its 256 workgroups, against the
+    draws-fastest pass on the same numbers."""
+    import torch
+
+    M = orc.tail_count(S, 1.0)
+    for N in (1, 15, 16, 17, 255, 4096 + 3, 16 * 256 * 2 + 31):
+        t = torch.empty((N, S), dtype=torch.float64, device="cuda")
+        eng.fill_synthetic(t, seed=77 + S + N, k_lo=0.05, k_hi=1.0)
+        view = t.T.contiguous().T if N > 1 else torch.as_strided(t.clone(), (N, S), (1, N))
+        assert view.stride(0) == 1 or N == 1
+        a = eng.psis_loo(view, M, "psis", 1.0, 0.7)
+        used = eng.last_kernels()
+        b = eng.psis_loo(t, M, "psis", 1.0, 0.7)
+        torch.cuda.synchronize()
+        if N > 1:
+            assert "tile_loo_kernel" in used, (S, N, used)
+        for key in ("diag", "loo_i", "lppd_i"):
+            np.testing.assert_allclose(a[key].cpu().numpy(), b[key].cpu().numpy(), rtol=1e-10, atol=1e-11, err_msg=f"{key} S={S} N={N}")
