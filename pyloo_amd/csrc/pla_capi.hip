@@ -50,7 +50,7 @@ struct pla_engine {
   // frozen: the workspace may be referenced by a captured HIP graph; a call that would have to reallocate any of
   // it returns PLA_ERR_FROZEN instead (pla_engine_set_frozen)
   bool frozen = false;
-  unsigned long long* counters = nullptr;  // [16] device: [0] rows on the slow list, [1] running total, [2..3] clock probe, [8..15] reasons (profiling builds)
+  unsigned long long* counters = nullptr;  // [16] device: [0] rows on the slow list, [1] running total, [2..3] clock probe, [4] group counter of the tile kernel (back to back), [8..15] reasons (profiling builds)
   double* d_red = nullptr;                 // reduction partials
   // staging for PLA_HOST callers (grown on demand)
   void* d_in = nullptr;

@@ -858,6 +858,7 @@ hipError_t launch_tile(const RowsParams& p, int dtype, int ks, hipStream_t strea
     if (e == hipSuccess) e = hipStreamWaitEvent(pipe->first, pipe->fork, 0);
     if (e == hipSuccess) e = hipStreamWaitEvent(pipe->second, pipe->fork, 0);
     if (e != hipSuccess) return e;
+    f.queue = sync;  // (groups beyond a workgroup's first: sync[0], zero at launch)
     f.done = sync + 48;
     static const char* wprio = getenv("PLA_WAVE_PRIO");
     f.prio = wprio ? atoi(wprio) : 3;
@@ -879,7 +880,9 @@ hipError_t launch_tile(const RowsParams& p, int dtype, int ks, hipStream_t strea
     if (e != hipSuccess) return e;
   } else {
     e = hipMemsetAsync(p.counters, 0, sizeof(unsigned long long), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(p.counters + 4, 0, sizeof(unsigned long long), stream);  // [4]: the kernel's group counter
     if (e != hipSuccess) return e;
+    f.queue = reinterpret_cast<unsigned*>(p.counters + 4);
     if (!tile_lds_attr<false>()) return hipErrorInvalidValue;
     hipLaunchKernelGGL((tile_loo_kernel<double, false>), dim3(g1), dim3(kTileThreads), sizeof(TileSmem<double, kTileCap>), stream, c, f,
                        p.tail_count);

@@ -81,7 +81,8 @@ struct TileSmem {
   double scal[kObs][2];                   // B -> C, D: provisional shift, threshold (both raw)
   unsigned cnt[kObs];                     // candidates seen (not capped)
   unsigned again;                         // D: observations of the group whose list came out too short or too long (bit per observation)
-  unsigned pad_[3];
+  unsigned next_group;                    // C: the group this workgroup sweeps next (streamed pass: taken from the launch's counter)
+  unsigned pad_[2];
   union {
     Sel sel[kTileSelWaves];               // B (histograms of the threshold search), D: scratch of one selection per selecting wave
     Sweep sweep;                          // C, and read at the very start of D
@@ -399,6 +400,14 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
     }
     __syncthreads();
 
+    // The groups after a workgroup's first come from a counter of the launch (F.queue, zero at launch), asked for
+    // at the start of the sweep they follow -- a whole sweep ahead of their use.  With the groups dealt out by blockIdx alone the
+    // streamed launch would depend on every workgroup being resident: the fit kernel's workgroups share the CUs, and one of this kernel's
+    // that found no room beside two of them would leave its groups unswept while they wait for those very groups.  This way
+    // a displaced workgroup's groups go to its neighbours.
+    // (Back to back, the same counter evens out what the second sweeps and the last round of groups leave uneven: 9.1-9.4 ->
+    // 8.8-8.9 ms on C3 when it came in.)
+    if (tid == 0 && redo == 0u) sm.next_group = gridDim.x + atomicAdd(F.queue, 1u);
     // ---- C. the sweep ---------------------------------------------------------------------------------------------------------
     const double nmp = -sm.scal[o][0], nt_raw = -sm.scal[o][1];
     double nmn = INF, nmx = -INF, s1 = 0.0, s2 = 0.0;  // min / max of ll = -(max / min of raw)
@@ -541,7 +550,7 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
     prev = g;
     prev_only = redo != 0u ? redo : 0xffffu;
     prev_first = redo == 0u;
-    g = redo != 0u ? resume : g + (int64_t)gridDim.x;
+    g = redo != 0u ? resume : (int64_t)sm.next_group;  // (written before the barrier above; a second sweep keeps the group it had in hand)
     redo = 0u;
   }
 }
