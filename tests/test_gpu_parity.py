@@ -845,3 +845,33 @@ def test_tile_kernel_row_lengths_and_group_counts(eng, S):
             assert "tile_loo_kernel" in used, (S, N, used)
         for key in ("diag", "loo_i", "lppd_i"):
             np.testing.assert_allclose(a[key].cpu().numpy(), b[key].cpu().numpy(), rtol=1e-10, atol=1e-11, err_msg=f"{key} S={S} N={N}")
+
+
+@pytest.mark.gpu
+def test_observations_fastest_pass_is_graph_capturable(eng):
+    """The streamed tile pass (two internal streams forked from and joined to the caller's, flags zeroed by a kernel of the
+    pass) captured in a HIP graph and replayed on new data in the same buffer."""
+    import torch
+
+    S, N = 4000, 5003
+    buf = torch.empty((S, N), dtype=torch.float64, device="cuda")
+    view = buf.T
+    t = torch.empty((N, S), dtype=torch.float64, device="cuda")
+    eng.fill_synthetic(t, seed=21)
+    buf.copy_(t.T)
+    warm = eng.psis_loo(view, 190, "psis", 1.0, 0.7)  # sizes the workspace, sets the kernel's LDS attribute
+    assert "tile_loo_kernel<SYNC>" in eng.last_kernels()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = eng.psis_loo(view, 190, "psis", 1.0, 0.7)
+    eng.fill_synthetic(t, seed=22)
+    buf.copy_(t.T)  # new matrix in the same buffer
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    fresh = eng.psis_loo(view, 190, "psis", 1.0, 0.7)
+    torch.cuda.synchronize()
+    for key in ("diag", "loo_i", "lppd_i", "agg"):
+        assert torch.equal(out[key], fresh[key]), key
+    assert not torch.equal(out["loo_i"], warm["loo_i"])
