@@ -238,7 +238,14 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
     }
     return again;
   };
-  const auto sample_step = [&](int j) { return (int)(((int64_t)(kTileWaves * j + w) * nit) / (kTileWaves * kPer)); };
+  // Every wave sweeps the row's steps cyclically from a start of its own, w / 8 of the way through the row.  The first 16
+  // steps a wave loads -- the head of its ring -- are then its part of the SAMPLE the thresholds come from: 16 clusters of four
+  // consecutive draws, 32 draws apart, from eight windows spread evenly over the row (at S = 4000 the eight windows tile the
+  // row: a cluster every 32 draws; every chain of a chain-major stack contributes).  Nothing is loaded for the sample alone
+  // (a sample of its own, read again by the sweep, was 11 % of the kernel's loads and of its HBM traffic).
+  static_assert(kPer <= PLA_TILE_RING, "the sample is the head of the ring");
+  const int start_w = (int)(((int64_t)w * nit) / kTileWaves);       // first step of this wave's sweep
+  const int ahead0 = (PLA_TILE_RING + start_w) % nit;                // the step of visit R
   // One trip of the loop: the sample loads of group g are ISSUED, the selection of the group before it runs on the lists in LDS
   // while they fly, then the sample is turned into thresholds and the group is swept.  (One place of issue for the sample; the
   // loop is entered with no group behind and left with none ahead.)
@@ -260,21 +267,22 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
           __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(gbase + (int64_t)step * step_bytes), 0, (int)0xfffffff0u, 0x00020000);
       return col_load<T>(rs, voff, 0);
     };
-    // ---- A. the sample: step floor((j + w / 8) nit / 16) for j < 16 -- 128 clusters of four consecutive draws, evenly spread -----
-    T sv[kPer];
-    if (have && !(PLA_TILE_ABLATE & 2)) {
-#pragma unroll
-      for (int j = 0; j < kPer; ++j) sv[j] = load_step(sample_step(j));
-    }
-    // ... and the first R steps of the sweep's ring behind them: in flight through the selection and the threshold search,
-    // so that the sweep starts on a full pipeline
-    // (steps past the row: the last whole step again -- a harmless hit in the cache; what they load is never looked at)
+    // ---- A. the first R steps of this wave's sweep, issued one group ahead: in flight through the selection of the group
+    // before, so that the threshold search finds its sample and the sweep a full pipeline.  (Visits past the row's last step
+    // come round to its first steps again: valid memory, never looked at.)
     constexpr int R = PLA_TILE_RING;
     T ring[R];
-    const int last = nit - 1;
+    const char* const rowend = gbase + (int64_t)nit * step_bytes;
+    int rs_records = (int)0xfffffff0u, rs_flags = 0x00020000;
+    asm volatile("" : "+s"(rs_records), "+s"(rs_flags));
     if (have) {
+      const char* at = gbase + (int64_t)start_w * step_bytes;
 #pragma unroll
-      for (int u = 0; u < R; ++u) ring[u] = load_step(u < last ? u : last);
+      for (int u = 0; u < R; ++u) {
+        ring[u] = col_load<T>(__builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(at), 0, rs_records, rs_flags), voff, 0);
+        at += step_bytes;
+        at = at == rowend ? gbase : at;
+      }
     }
     if (prev >= 0) {  // (ends on a barrier: the lists of the group before are free for this group's sample)
       const unsigned again = select_group(prev, prev_only, prev_first);
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
     } else if constexpr (!(PLA_TILE_ABLATE & 2)) {
 #pragma unroll
       for (int j = 0; j < kPer; ++j)  // rounded up: the threshold may only err towards FEWER candidates by what one float ulp is worth
-        sm.keys[o][(w * kSub + dsub) * kPer + j] = __double2float_ru(-(double)sv[j]);
+        sm.keys[o][(w * kSub + dsub) * kPer + j] = __double2float_ru(-(double)ring[j]);
       __syncthreads();
       // ---- B. threshold and provisional shift: a wave per observation, kSelPer observations side by side ------------------------
       // The sample's ks-th largest value to 1/4096 of the sample's range, by counting: a 64-bin histogram of the eight keys a
@@ -495,10 +503,7 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
       // that left the sweep waiting on HBM latency, 48 KB per CU outstanding where ~100 KB are needed).
       static_assert(R % kPF == 0, "pipeline slots are assigned at compile time");
       const int nmain = (nit / R) * R;
-      const char* ahead = gbase + (int64_t)R * step_bytes;   // where step base + R + u lies
-      const char* const endp = gbase + (int64_t)last * step_bytes;
-      int rs_records = (int)0xfffffff0u, rs_flags = 0x00020000;
-      asm volatile("" : "+s"(rs_records), "+s"(rs_flags));
+      const char* ahead = gbase + (int64_t)ahead0 * step_bytes;   // where visit base + R + u lies
       // (the pipeline starts on kPF draws that count nothing: table entry 0 x 2^0 = 0.0 times a polynomial of 1, stored to the dump slot)
 #pragma unroll
       for (int u = 0; u < kPF; ++u) {
@@ -514,12 +519,11 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
         for (int u = 0; u < R; ++u) {
           stage_b(u % kPF);
           stage_a((double)ring[u], u % kPF);
-          // the step R ahead, through a running pointer (the last whole step again once the row is through)
-          const bool in = base + (R + u) < last;
-          const char* at = in ? ahead : endp;
-          asm volatile("" : "+s"(at));
-          ring[u] = col_load<T>(__builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(at), 0, rs_records, rs_flags), voff, 0);
+          // the visit R ahead, through a running pointer that comes round at the row's end
+          asm volatile("" : "+s"(ahead));
+          ring[u] = col_load<T>(__builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ahead), 0, rs_records, rs_flags), voff, 0);
           ahead += step_bytes;
+          ahead = ahead == rowend ? gbase : ahead;
           __builtin_amdgcn_sched_barrier(0);
         }
       }
