@@ -28,7 +28,7 @@ namespace pla {
 #define PLA_TILE_CAP 640   // candidate list capacity per observation
 #endif
 #ifndef PLA_TILE_RING
-#define PLA_TILE_RING 24   // steps in flight per lane
+#define PLA_TILE_RING 16   // steps in flight per lane (= the sample's 16: C3 8.0-8.3 ms; 18: the same; 20: 8.4-8.5; 24: 8.6-8.8; 32: 8.45)
 #endif
 #ifndef PLA_TILE_PF
 #define PLA_TILE_PF 4      // depth of the sweep's software pipeline (draws between a draw's LDS requests and their use)
