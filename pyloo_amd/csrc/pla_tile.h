@@ -9,8 +9,8 @@
 // load reads the pieces of four consecutive draws, the eight waves cover 32 draws per step.  32 lanes work on every
 // observation, so its candidates fit the CU: 16 lists of 640 entries in LDS, appended to with LDS atomics, and the selection
 // of the split pass (wave_select_split, pla_wave.h) runs on them in place, two observations per wave -- nothing but the
-// hand-over to fit_rows_kernel goes back to HBM.  The threshold sample (512 draws spread over the row, 16 per lane) is read a
-// second time by the sweep, but the 16 MB of samples the 256 resident workgroups hold at a time never leave the Infinity Cache.
+// hand-over to fit_rows_kernel goes back to HBM.  The threshold sample (512 draws spread over the row, 16 per lane) is the
+// head of the sweep itself: every wave starts its cyclic walk over the row at a place of its own.
 //
 //   per group of 16 observations:
 //   A  sample: 16 draws per lane, spread over the row (every chain of a chain-major stack contributes), as f32 keys to LDS
