@@ -33,9 +33,6 @@ namespace pla {
 #ifndef PLA_TILE_PF
 #define PLA_TILE_PF 4      // depth of the sweep's software pipeline (draws between a draw's LDS requests and their use)
 #endif
-#ifndef PLA_TILE_MASKED
-#define PLA_TILE_MASKED 0  // list appends under the execution mask (0: every lane, the others on private dump counters / slots)
-#endif
 #ifndef PLA_TILE_ABLATE
 #define PLA_TILE_ABLATE 0  // timing experiments (tools/build_alt.sh): 1 no selection, 2 no sample / threshold, 4 sweep = loads + min only, 8 no list appends, 16 no exponentials
 #endif
@@ -447,14 +444,10 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
       ptt[sl] = *reinterpret_cast<const int4*>(tabc + byte0_shl(k, four));
       // candidate: a slot of the observation's list from its counter (32 lanes in 8 waves append to one list); everybody else
       // counts on a private counter that starts past the end of any list, and stores to a private slot: no control flow
+      // (as `if (candidate)` every draw becomes a region of its own and the pipeline's registers spill: 256 + 148)
       const bool cand = ll <= nt_raw;                  // raw >= threshold
       if constexpr ((PLA_TILE_ABLATE & 8) != 0) {
         nmx = vmax_nc<false>(nmx, cand ? 1.0 : 2.0);
-      } else if constexpr (PLA_TILE_MASKED != 0) {
-        // only the lanes that hold a candidate (one in ten) take part in the atomic: the LDS serves an atomic lane by lane
-        unsigned pos = 0xffffffffu;
-        if (cand) pos = __hip_atomic_fetch_add(mycnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        ppos[sl] = pos;
       } else if constexpr ((PLA_TILE_ABLATE & 64) != 0) {
         ppos[sl] = cand ? 0xffffffffu : 0xfffffff0u;
       } else {
@@ -483,9 +476,7 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
       s1 = fma(__hiloint2double(mad_i24(k, c4096, ptt[sl].y), ptt[sl].x), fma(rr, O, E), s1);
       s2 = fma(__hiloint2double(mad_i24(k, cm4096, ptt[sl].w), ptt[sl].z), fma(-rr, O, E), s2);
       if constexpr (!(PLA_TILE_ABLATE & 8)) {
-        if constexpr (PLA_TILE_MASKED != 0) {
-          if (ppos[sl] < (unsigned)kCap) mylist[ppos[sl]] = (T)pll[sl];
-        } else if constexpr ((PLA_TILE_ABLATE & 32) != 0) {
+        if constexpr ((PLA_TILE_ABLATE & 32) != 0) {
           nmx = vmax_nc<false>(nmx, ppos[sl] < (unsigned)kCap ? 1.0 : 2.0);
         } else {
           *(ppos[sl] < (unsigned)kCap ? &mylist[ppos[sl]] : mydumpv) = (T)pll[sl];
