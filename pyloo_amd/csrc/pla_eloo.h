@@ -660,17 +660,31 @@ __device__ __forceinline__ int qbin_of(double x, double x0, double scale) {
   const int b = (int)((x - x0) * scale);
   return b < 0 ? 0 : (b > kQBins - 1 ? kQBins - 1 : b);
 }
+// Scratch of one hist_select call.  Two of them take turns: a call leaves its results in its own and resets the OTHER one for the
+// call after it, so that no barrier is spent on "everybody has read this before it is written again" -- four per call, not seven.
+struct HistSelectScratch {
+  double red[4];  // [0] mass below the bin / below the draw, [1] the bin (-1: none), [2] mass at the draw
+  QuantList ql;
+};
+__device__ __forceinline__ void hist_select_reset(HistSelectScratch* h) {
+  h->red[1] = -1.0;
+  h->ql.count = 0;
+  h->ql.best = ~0ull;
+}
+// `mine` must have been reset (by the call before, or by the caller ahead of a barrier); `other` is reset here for the next call.
 template <int BLOCK, class Each>
 __device__ __forceinline__ int hist_select(Each each, const double target, const double* cum, const double x0, const double scale,
-                                           double* red, QuantList* ql, uint64_t* key_out, double* below, double* at) {
+                                           HistSelectScratch* mine, HistSelectScratch* other, uint64_t* key_out, double* below, double* at) {
   const int tid = threadIdx.x;
   constexpr int PER = kQBins / BLOCK;
-  if (tid == 0) {
-    red[1] = -1.0;
-    ql->count = 0;
-    ql->best = ~0ull;
-  }
-  __syncthreads();
+  double* const red = mine->red;
+  QuantList* const ql = &mine->ql;
+  // (the rare ways out: the other scratch is reset behind a barrier of its own)
+  const auto leave = [&](const int code) {
+    if (tid == 0) hist_select_reset(other);
+    __syncthreads();
+    return code;
+  };
   {  // the bin in which the running sum first reaches the target (exactly one thread finds it)
     double prev = tid == 0 ? 0.0 : cum[tid * PER - 1];
 #pragma unroll
@@ -686,8 +700,7 @@ __device__ __forceinline__ int hist_select(Each each, const double target, const
   __syncthreads();
   const int tb = (int)red[1];
   const double base = red[0];
-  __syncthreads();
-  if (tb < 0) return 0;
+  if (tb < 0) return leave(0);
   each([&](const uint64_t k, const double mass) {
     if (qbin_of(val_of(k), x0, scale) == tb) {
       const int idx = atomicAdd(&ql->count, 1);
@@ -699,32 +712,32 @@ __device__ __forceinline__ int hist_select(Each each, const double target, const
   });
   __syncthreads();
   const int n = ql->count;
-  if (n > 256) return -1;
-  uint64_t mine = ~0ull;
+  if (n > 256) return leave(-1);
+  uint64_t mykey = ~0ull;
   double upto = base, under = base;
   if (tid < n) {
-    mine = ql->key[tid];
+    mykey = ql->key[tid];
     for (int j = 0; j < n; ++j) {
       const uint64_t kj = ql->key[j];
       const double mj = ql->mass[j];
-      upto += (kj <= mine) ? mj : 0.0;
-      under += (kj < mine) ? mj : 0.0;
+      upto += (kj <= mykey) ? mj : 0.0;
+      under += (kj < mykey) ? mj : 0.0;
     }
   }
   const bool reaches = tid < n && upto >= target;
-  if (reaches) atomicMin(&ql->best, (unsigned long long)mine);
+  if (reaches) atomicMin(&ql->best, (unsigned long long)mykey);
   __syncthreads();
   const uint64_t best = (uint64_t)ql->best;
-  if (best == ~0ull) return -1;  // (rounding at the bin's edge: let the radix descent decide)
-  if (reaches && mine == best) {  // (equal draws compute the same two numbers)
+  if (best == ~0ull) return leave(-1);  // (rounding at the bin's edge: let the radix descent decide)
+  if (reaches && mykey == best) {  // (equal draws compute the same two numbers)
     red[0] = under;
     red[2] = upto - under;
   }
+  if (tid == 0) hist_select_reset(other);
   __syncthreads();
   *key_out = best;
   *below = red[0];
   *at = red[2];
-  __syncthreads();
   return 1;
 }
 
@@ -742,7 +755,8 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 1) void e_loo_quantile_kernel(EQu
   __shared__ __attribute__((aligned(32))) double hist[256];
   __shared__ double red[BLOCK / kWave > 4 ? BLOCK / kWave : 4];
   __shared__ double mix[4 * (BLOCK / kWave)];
-  __shared__ QuantList qlist;
+  __shared__ QuantList qlist;             // (the radix descent's)
+  __shared__ HistSelectScratch hsel[2];   // (hist_select's, in turns)
   const int tid = threadIdx.x;
   const int S = P.n_draws;
   const int64_t n_rows = (!FAST && P.slow_list) ? (int64_t)*P.slow_count : P.n_obs;
@@ -898,8 +912,10 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 1) void e_loo_quantile_kernel(EQu
       const double off = scan[tid];
 #pragma unroll
       for (int i = 0; i < PER; ++i) cum2k[tid * PER + i] = off + loc[i];
+      if (tid == 0) hist_select_reset(&hsel[0]);
       __syncthreads();
     }
+    int turn = 0;  // whose turn it is among hist_select's two scratches
     for (int ip = 0; ip < P.n_probs && !declined; ++ip) {
       const double prob = P.probs[ip];
       double res;
@@ -909,7 +925,8 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 1) void e_loo_quantile_kernel(EQu
         // np.quantile(x, prob), method "linear": virtual index (S - 1) prob between the order statistics lo and lo + 1
         const double virt = (double)(S - 1) * prob;
         const double lo = floor(virt), t = virt - lo;
-        int hs = hist_ok ? hist_select<BLOCK>(each_count, lo + 1.0, cum2k, xmin, qscale, red, &qlist, &kv, &below, &at) : -1;
+        int hs = hist_ok ? hist_select<BLOCK>(each_count, lo + 1.0, cum2k, xmin, qscale, &hsel[turn], &hsel[turn ^ 1], &kv, &below, &at) : -1;
+        turn ^= hist_ok ? 1 : 0;
         if constexpr (FAST) {
           if (hs < 0) {
             declined = true;
@@ -931,7 +948,8 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 1) void e_loo_quantile_kernel(EQu
         res = (t >= 0.5) ? b - diff * (1.0 - t) : a + diff * t;                           // numpy's _lerp
         if (t == 0.0) res = a;
       } else {
-        const int hs = hist_ok ? hist_select<BLOCK>(each, prob * wtot, cum2k, xmin, qscale, red, &qlist, &kv, &below, &at) : -1;
+        const int hs = hist_ok ? hist_select<BLOCK>(each, prob * wtot, cum2k, xmin, qscale, &hsel[turn], &hsel[turn ^ 1], &kv, &below, &at) : -1;
+        turn ^= hist_ok ? 1 : 0;
         bool found = hs == 1;
         if constexpr (FAST) {
           if (hs < 0) {
@@ -962,11 +980,12 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 1) void e_loo_quantile_kernel(EQu
           // member has x1 == x_sorted[wi] and returns v exactly.  (Collapsing the group into one draw of the combined weight
           // gave 4.36 where the reference gives 5.0 on count data.)  The reference's order inside the group is that of an
           // unstable argsort; here it is draw order: the first member is the tied draw with the lowest index.
-          double wfirst = 0.0;
+          // (its weight: the one thread that holds that draw says so -- one barrier; mix[] is free behind block_reduce_mix)
           each_s([&](const uint64_t, const double w, const int si) {
-            if ((double)si == sfirst) wfirst = w;
+            if ((double)si == sfirst) mix[0] = w;
           });
-          wfirst = block_reduce<OpSum, BLOCK>(wfirst, red);
+          __syncthreads();
+          const double wfirst = mix[0];
           if (below == 0.0 && prev == -pinf()) res = v;                                   // wi == 0: 548-550
           else if (!(below + wfirst >= prob * wtot)) res = v;                             // crossed inside the group of equal draws
           else {
