@@ -13,9 +13,13 @@ What runs where:
 * the survey-sampling estimators (``estimators/difference.py:60-112``, ``hansen_hurwitz.py:61-91``,
   ``srs.py:62-84``): a few vector operations on ``m`` numbers, host.
 
+* the ``log_p`` / ``log_q`` posterior correction (loo_subsample.py:333-370): ``importance_resample`` smooths the ratios on
+  the device and draws with the reference's generator calls; the sampled rows are gathered with their draws re-drawn (a
+  copy of ``m`` rows) and go through the same two passes.
+
 Not carried over: ``loo_approximation="plpd"`` with a user log-likelihood function (needs the model; without one the
-reference falls back to the mean log-likelihood, which is what "plpd" does here, with the same warning), the
-``log_p`` / ``log_q`` posterior correction and ``update_subsample`` (loo_approximate_posterior.py is outside SURVEY §8).
+reference falls back to the mean log-likelihood, which is what "plpd" does here, with the same warning) and
+``update_subsample``.
 """
 
 import warnings
@@ -162,10 +166,64 @@ def _approximation(eng, matrix, kind, n_draws):
     return _to_host(res["lppd_i"] if kind == "lpd" else res["loo_i"]).astype(np.float64)
 
 
+def importance_resample(log_p, log_q, method="psis", seed=None):
+    """Indices of the draws after importance resampling from an approximate posterior
+    (``loo_approximate_posterior.importance_resample``, loo_approximate_posterior.py:437-536, as ``loo_subsample`` calls it at
+    loo_subsample.py:341-346): the log ratios ``log_p - log_q`` are Pareto-smoothed (``"psis"``: then drawn WITHOUT
+    replacement, i.e. a weighted permutation of the draws; ``"psir"``: with replacement) or only normalised (``"sis"``), and
+    ``numpy.random.RandomState(seed).choice`` draws as many indices as there are draws.  The smoothing runs on the device
+    (``pla_importance_weights``); the generator, its fall-backs and the warnings are the reference's.  Non-finite ratios end as
+    they do there -- in the exception numpy raises when the map back to the original positions runs out of bounds -- which
+    ``loo_subsample`` reports as its "Importance resampling failed" warning."""
+    log_p = np.asarray(log_p, dtype=np.float64)
+    log_q = np.asarray(log_q, dtype=np.float64)
+    rng = np.random.RandomState(seed) if seed is not None else np.random.RandomState()
+    draws = len(log_p)
+    logiw = log_p - log_q
+    valid_idx = np.isfinite(logiw)
+    if not np.all(valid_idx):
+        warnings.warn(f"Found {np.sum(~valid_idx)} non-finite importance weights. These will be excluded.", UserWarning, stacklevel=2)
+        if np.sum(valid_idx) == 0:
+            raise ValueError("No valid importance weights found.")
+        logiw = logiw[valid_idx]
+    else:
+        valid_idx = slice(None)
+    replace = method == "psir"
+    if method in ["psis", "psir"]:
+        try:
+            n = len(logiw)
+            lw, _ = get_engine(None).importance_weights(np.ascontiguousarray(logiw.reshape(1, n)), tail_count_for(n, 1.0),
+                                                        ISMethod.PSIS.value)
+            logiw = np.asarray(lw, dtype=np.float64).reshape(n)
+        except Exception as e:  # noqa: BLE001  (the reference's own catch-all around psislw)
+            warnings.warn(f"PSIS smoothing failed: {str(e)}.", UserWarning, stacklevel=2)
+    else:
+        m = np.max(logiw)
+        logiw = logiw - (m + np.log(np.sum(np.exp(logiw - m))))
+    with np.errstate(over="ignore"):
+        p = np.exp(logiw)
+    p = p / np.sum(p)
+    try:
+        indices_subset = rng.choice(draws, size=draws, replace=replace, p=p)
+    except ValueError as e:
+        if "Fewer non-zero entries in p than size" in str(e) and not replace:
+            warnings.warn("Not enough non-zero weights for sampling without replacement. Switching to sampling with replacement.",
+                          UserWarning, stacklevel=2)
+            indices_subset = rng.choice(draws, size=draws, replace=True, p=p)
+        else:
+            warnings.warn(f"Resampling failed: {str(e)}. Using random indices.", UserWarning, stacklevel=2)
+            indices_subset = rng.choice(draws, size=draws)
+    if isinstance(valid_idx, np.ndarray):
+        return np.where(valid_idx)[0][indices_subset]
+    return indices_subset
+
+
 def loo_subsample_from_matrix(log_likelihood, observations=100, loo_approximation="lpd", estimator="diff_srs",
-                              loo_approximation_draws=None, reff=1.0, scale=None, pointwise=False):
+                              loo_approximation_draws=None, reff=1.0, scale=None, pointwise=False, draw_index=None):
     """Subsampled PSIS-LOO from an ``(n_obs, n_draws)`` matrix (NumPy array, or torch CUDA tensor: device-resident, the
-    sampled rows are read in place).  Returns ``(ELPDData, SubsampleIndices, Estimate)``; see :func:`loo_subsample`."""
+    sampled rows are read in place).  ``draw_index``: the draws of the SAMPLED rows are taken in this order / multiplicity before
+    PSIS-LOO and the variance over draws (the posterior correction, loo_subsample.py:348-356).
+    Returns ``(ELPDData, SubsampleIndices, Estimate)``; see :func:`loo_subsample`."""
     kind = str(loo_approximation).lower()
     if kind not in APPROXIMATIONS:
         raise ValueError(f"Invalid loo_approximation '{loo_approximation}'. Must be one of: {', '.join(APPROXIMATIONS)}")
@@ -200,7 +258,19 @@ def loo_subsample_from_matrix(log_likelihood, observations=100, loo_approximatio
     M = tail_count_for(n_samples, reff)
     if M + 1 > n_samples:
         raise IndexError(f"index {-M - 1} is out of bounds for axis 0 with size {n_samples}")
-    if _is_torch_tensor(log_likelihood):  # resident matrix: the sampled rows are read in place
+    if draw_index is not None and _is_torch_tensor(log_likelihood):  # the m sampled rows with their draws re-drawn: a small copy
+        import torch
+
+        rows_t = torch.as_tensor(np.asarray(indices.idx), device=log_likelihood.device, dtype=torch.long)
+        draws_t = torch.as_tensor(np.asarray(draw_index), device=log_likelihood.device, dtype=torch.long)
+        sub = log_likelihood.index_select(0, rows_t).index_select(1, draws_t).contiguous()
+        res = eng.psis_loo(sub, M, ISMethod.PSIS.value, scale_value, good_k, aggregate=False)
+        var_m = eng.waic(sub, 1.0, aggregate=False)["var_i"]
+    elif draw_index is not None:
+        sub = np.ascontiguousarray(np.asarray(log_likelihood)[indices.idx][:, np.asarray(draw_index)])
+        res = eng.psis_loo(sub, M, ISMethod.PSIS.value, scale_value, good_k, aggregate=False)
+        var_m = eng.waic(sub, 1.0, aggregate=False)["var_i"]
+    elif _is_torch_tensor(log_likelihood):  # resident matrix: the sampled rows are read in place
         res = eng.psis_loo(log_likelihood, M, ISMethod.PSIS.value, scale_value, good_k, aggregate=False, rows=indices.idx)
         var_m = eng.waic(log_likelihood, 1.0, aggregate=False, rows=indices.idx)["var_i"]
     else:  # host matrix (possibly an observations-fastest view): only the m sampled rows travel
@@ -282,9 +352,6 @@ def loo_subsample(data, observations=100, loo_approximation="plpd", estimator="d
     """Approximate LOO-CV for large data by subsampling, with ``pyloo.loo_subsample``'s parameters, warnings and result
     layout (loo_subsample.py:37-607).  ``observations``: number of observations to draw, an integer index array, or
     ``None`` for the full ``loo()``."""
-    if log_p is not None or log_q is not None:
-        raise NotImplementedError("the log_p / log_q posterior correction (loo_subsample.py:333-370) is outside the scope "
-                                  "of pyloo_amd")
     idata = to_inference_data(data)
     log_likelihood = get_log_likelihood(idata, var_name=var_name)
     pointwise = rcParams["stats.ic_pointwise"] if pointwise is None else pointwise
@@ -301,8 +368,19 @@ def loo_subsample(data, observations=100, loo_approximation="plpd", estimator="d
     matrix = _replace_nan(matrix)
     if observations is None:  # loo_subsample.py:252-259
         return loo(data=data, pointwise=pointwise, var_name=var_name, reff=reff, scale=scale)
+    draw_index = None
+    if log_p is not None and log_q is not None:  # posterior correction: loo_subsample.py:333-370
+        if len(log_p) != len(log_q):
+            raise ValueError(f"log_p and log_q must have the same length, got {len(log_p)} and {len(log_q)}")
+        try:
+            draw_index = importance_resample(log_p=log_p, log_q=log_q, method=resample_method, seed=seed)
+            if len(draw_index) and (np.min(draw_index) < 0 or np.max(draw_index) >= n_samples):
+                raise IndexError(f"index {int(np.max(draw_index))} is out of bounds for axis 0 with size {n_samples}")
+        except Exception as e:  # noqa: BLE001  (the reference's catch-all: loo_subsample.py:363-370)
+            warnings.warn(f"Importance resampling failed: {str(e)}. Falling back to original samples.", UserWarning, stacklevel=2)
+            draw_index = None
     out, indices, estimates = loo_subsample_from_matrix(matrix, observations, kind, estimator, loo_approximation_draws,
-                                                        reff, scale, pointwise)
+                                                        reff, scale, pointwise, draw_index=draw_index)
     if pointwise:
         out["loo_i"] = wrap_obs(np.asarray(out["loo_i"]), obs_shape, obs_dims, coords, "loo_i")
     # what update_subsample() of the reference reads back (loo_subsample.py:589-596)

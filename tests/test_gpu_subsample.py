@@ -123,3 +123,61 @@ def test_sampling_every_observation_reproduces_loo():
             assert out["subsampling_SE"] == 0.0  # the whole population was observed
         scaled, _, _ = pl.loo_subsample_from_matrix(t, np.arange(N), "lpd", "srs", scale="deviance")
         np.testing.assert_allclose(scaled["elpd_loo"], -2 * ref["elpd_loo"], rtol=1e-12)
+
+
+def test_importance_resample_draws_the_reference_indices():
+    """``importance_resample`` (loo_approximate_posterior.py:437-536, used by the posterior correction of ``loo_subsample``)
+    against index arrays the reference's function returned for the same ``log_p`` / ``log_q`` / method / seed
+    (tests/golden/make_golden_resample.py): smoothing on the device, the generator calls the reference's."""
+    from conftest import load_golden
+    from pyloo_amd.loo_subsample import importance_resample
+
+    g = load_golden("resample")
+    for i, case in enumerate(g["cases"]):
+        method, seed = str(case).split(":")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            idx = importance_resample(g[f"c{i}_log_p"], g[f"c{i}_log_q"], method=method, seed=int(seed))
+        want = g[f"c{i}_idx"]
+        assert idx.shape == want.shape
+        # (the probabilities agree to ~1e-12 with the reference's: a draw changes only where a uniform number falls that close
+        # to a boundary of the cumulative weights)
+        assert np.mean(idx == want) >= 0.999, (case, np.mean(idx == want))
+        if method != "psir":
+            assert len(np.unique(idx)) == len(idx)  # without replacement: a permutation of the draws
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(Exception) as err:  # non-finite ratios: the reference's function ends in this exception as well
+            importance_resample(g["nonfinite_log_p"], g["nonfinite_log_q"], method="psis", seed=17)
+    assert type(err.value).__name__ == str(g["nonfinite_raises"])
+
+
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_posterior_correction_re_draws_the_sampled_rows(where):
+    """loo_subsample.py:333-370: with ``log_p`` / ``log_q`` the draws of the SAMPLED rows are re-drawn before PSIS-LOO and the
+    variance over draws.  "psis" draws without replacement -- a permutation, which PSIS-LOO does not see; "psir" draws with
+    replacement: against the oracle on the matrix gathered on the host."""
+    import torch
+
+    from pyloo_amd.loo_subsample import importance_resample, loo_subsample_from_matrix
+
+    N, S, m = 300, 2000, 40
+    ll = make_ll(N, S, np.float64, 99)
+    rng = np.random.default_rng(5)
+    log_q = rng.normal(size=S)
+    log_p = log_q + rng.standard_t(df=5, size=S)
+    obs = np.sort(rng.permutation(N)[:m])
+    src = torch.as_tensor(ll).cuda() if where == "device" else ll
+    base, _, _ = loo_subsample_from_matrix(src, obs, "lpd", "diff_srs", None, 1.0, None, True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        perm = importance_resample(log_p, log_q, method="psis", seed=3)
+        boot = importance_resample(log_p, log_q, method="psir", seed=3)
+        a, _, _ = loo_subsample_from_matrix(src, obs, "lpd", "diff_srs", None, 1.0, None, True, draw_index=perm)
+        b, _, _ = loo_subsample_from_matrix(src, obs, "lpd", "diff_srs", None, 1.0, None, True, draw_index=boot)
+    np.testing.assert_allclose(a["elpd_loo"], base["elpd_loo"], rtol=1e-9)
+    np.testing.assert_allclose(a["p_loo"], base["p_loo"], rtol=1e-7)
+    ref = orc.loo_arrays(ll[obs][:, boot], 1.0)
+    got = np.asarray(b["loo_i"])
+    assert np.count_nonzero(np.isfinite(got)) >= m
+    np.testing.assert_allclose(got[obs], ref["loo_i"], rtol=1e-8, atol=1e-10)

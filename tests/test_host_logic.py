@@ -260,3 +260,31 @@ def test_loo_i(ll8, monkeypatch):  # test_loo_i.py of the reference: layout, val
         pl.loo_i(0, d, reff=1.0, method="nope")
     with pytest.raises(TypeError, match="Valid scale values"):
         pl.loo_i(0, d, reff=1.0, scale="nope")
+
+
+def test_loo_subsample_posterior_correction(monkeypatch, oracle_engine):
+    """loo_subsample.py:333-370 through the front: ``log_p`` / ``log_q`` re-draw the draws of the sampled rows ("psis": a
+    weighted permutation -- the estimates stay what they are without it), unequal lengths are refused, and a resampling that
+    fails (non-finite ratios: the reference's own function ends in an exception there) falls back with the reference's warning."""
+    import importlib
+
+    ls = importlib.import_module("pyloo_amd.loo_subsample")
+    monkeypatch.setattr(ls, "get_engine", lambda device=None: oracle_engine)
+    rng = np.random.default_rng(3)
+    ll = -0.4 * rng.exponential(size=(60, 2000)) - 2.0
+    log_q = rng.normal(size=2000)
+    log_p = log_q + 0.5 * rng.normal(size=2000)
+    obs = np.arange(0, 60, 3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plain = pl.loo_subsample(idata(ll), observations=obs, loo_approximation="lpd", reff=1.0)
+        corrected = pl.loo_subsample(idata(ll), observations=obs, loo_approximation="lpd", reff=1.0, log_p=log_p, log_q=log_q, seed=5)
+    np.testing.assert_allclose(corrected["elpd_loo"], plain["elpd_loo"], rtol=1e-10)
+    np.testing.assert_allclose(corrected["p_loo"], plain["p_loo"], rtol=1e-8)
+    with pytest.raises(ValueError, match="log_p and log_q must have the same length, got 2000 and 1999"):
+        pl.loo_subsample(idata(ll), observations=obs, loo_approximation="lpd", reff=1.0, log_p=log_p, log_q=log_q[:-1])
+    bad = log_p.copy()
+    bad[[4, 9]] = [np.inf, np.nan]
+    with pytest.warns(UserWarning, match="Importance resampling failed: .* Falling back to original samples."):
+        fell_back = pl.loo_subsample(idata(ll), observations=obs, loo_approximation="lpd", reff=1.0, log_p=bad, log_q=log_q, seed=5)
+    np.testing.assert_allclose(fell_back["elpd_loo"], plain["elpd_loo"], rtol=1e-12)
