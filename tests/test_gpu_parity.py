@@ -875,3 +875,24 @@ def test_observations_fastest_pass_is_graph_capturable(eng):
     for key in ("diag", "loo_i", "lppd_i", "agg"):
         assert torch.equal(out[key], fresh[key]), key
     assert not torch.equal(out["loo_i"], warm["loo_i"])
+
+
+@pytest.mark.gpu
+def test_tile_kernel_on_a_window_of_a_wider_buffer(eng):
+    """Observations fastest, but the matrix is a window of a wider buffer: the draws lie further apart than there are
+    observations and the first observation is not on a 128-byte boundary (pieces then straddle cache lines: slower, not wrong)."""
+    import torch
+
+    S, N, pad = 4000, 20_003, 7
+    t = torch.empty((N, S), dtype=torch.float64, device="cuda")
+    eng.fill_synthetic(t, seed=4242, k_lo=0.05, k_hi=1.0)
+    wide = torch.full((S, N + pad), -1.0, dtype=torch.float64, device="cuda")
+    wide[:, 3:3 + N] = t.T
+    view = wide[:, 3:3 + N].T
+    assert view.stride(0) == 1 and view.stride(1) == N + pad and view.data_ptr() % 128 != 0
+    a = eng.psis_loo(view, 190, "psis", 1.0, 0.7)
+    assert "tile_loo_kernel" in eng.last_kernels()
+    b = eng.psis_loo(t, 190, "psis", 1.0, 0.7)
+    torch.cuda.synchronize()
+    for key in ("diag", "loo_i", "lppd_i"):
+        np.testing.assert_allclose(a[key].cpu().numpy(), b[key].cpu().numpy(), rtol=1e-10, atol=1e-11, err_msg=key)
