@@ -98,6 +98,26 @@ def launch_ranks(n):
         return 124
 
 
+def resolve_workload(args):
+    """BASELINE.json presets and the label of the workload: fills args.obs / draws / dtype / seed from --config, labels the
+    default workload on a whole node as C4, and returns (label, (heavy_lo, heavy_hi), k_hi) for the generator."""
+    heavy = (0.0, 0.0)
+    k_hi = 0.60
+    if args.config == "C2":
+        args.obs, args.draws, args.dtype, args.seed = 100_000, 4000, "f64", 0x5EED0002
+    elif args.config in ("C3", "C4"):
+        args.obs, args.draws, args.dtype = 1_000_000, 4000, "f64"
+        args.seed = 0x5EED0003 if args.config == "C3" else 0x5EED0004
+    elif args.config == "C5":  # SURVEY section 8(d): 70 % rows k ~ U(0.05, 0.5), 30 % rows k ~ U(1.0, 1.3)
+        args.obs, args.draws, args.dtype, args.seed = 125_000, 20000, "f32", 0x5EED0005
+        heavy, k_hi = (1.0, 1.3), 0.5
+    if args.config is None and args.gpus == 8 and (args.draws, args.dtype, args.obs, args.seed) == (4000, "f64", 1_000_000, 0x5EED0003):
+        # the default workload on a whole node IS BASELINE.json's C4 (8 M x 4000 f64, observation-sharded): its seed and label
+        args.config, args.seed = "C4", 0x5EED0004
+    label = args.config or ("C3" if (args.draws, args.dtype, args.obs) == (4000, "f64", 1_000_000) else "custom")
+    return label, heavy, k_hi
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,20 +140,7 @@ def main():
                     help="BASELINE.json preset (per-GPU shard): C2 = 1e5 x 4000 f64, C3 / C4 = 1e6 x 4000 f64 per GPU, "
                          "C5 = 125 000 x 20 000 f32 per GPU with 30 %% heavy-tailed rows")
     args = ap.parse_args()
-    heavy = (0.0, 0.0)
-    k_hi = 0.60
-    if args.config == "C2":
-        args.obs, args.draws, args.dtype, args.seed = 100_000, 4000, "f64", 0x5EED0002
-    elif args.config in ("C3", "C4"):
-        args.obs, args.draws, args.dtype = 1_000_000, 4000, "f64"
-        args.seed = 0x5EED0003 if args.config == "C3" else 0x5EED0004
-    elif args.config == "C5":  # 70 % rows k ~ U(0.05, 0.5), 30 % rows k ~ U(1.0, 1.3)
-        args.obs, args.draws, args.dtype, args.seed = 125_000, 20000, "f32", 0x5EED0005
-        heavy, k_hi = (1.0, 1.3), 0.5
-    if args.config is None and args.gpus == 8 and (args.draws, args.dtype, args.obs, args.seed) == (4000, "f64", 1_000_000, 0x5EED0003):
-        # the default workload on a whole node IS BASELINE.json's C4 (8 M x 4000 f64, observation-sharded): its seed and label
-        args.config, args.seed = "C4", 0x5EED0004
-    label = args.config or ("C3" if (args.draws, args.dtype, args.obs) == (4000, "f64", 1_000_000) else "custom")
+    label, heavy, k_hi = resolve_workload(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: this process has not touched torch or HIP yet, so it only
@@ -162,6 +169,7 @@ def main():
             dist.init_process_group(backend)
         assert dist.get_world_size() == args.gpus
 
+    from pyloo_amd import _capi
     from pyloo_amd.base import tail_count_for
     from pyloo_amd.engine import get_engine
     from pyloo_amd.sharded import all_reduce_aggregates, all_reduce_aggregates_device
@@ -216,6 +224,7 @@ def main():
     k_ms, k_n = eng.kernel_ms()
     f_ms, f_n = eng.first_kernel_ms()
     eng.set_timing(False)
+    gave_up = eng.stream_gave_up()  # streamed passes in which the fit kernel stopped waiting for the sweep (0 in a healthy run)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -264,6 +273,11 @@ def main():
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
+        # run-time switches in force: what this process's environment sets and what the library itself reads of it
+        # (pla_env_overrides; experiment knobs exist only in -DPLA_EXPERIMENT builds, which announce themselves here)
+        "env_overrides": sorted(f"{k}={v}" for k, v in os.environ.items() if k.startswith(("PLA_", "PYLOO_AMD_"))),
+        "library_env_overrides": _capi.env_overrides(),
+        "stream_gave_up": gave_up,
         "config": {
             "workload": f"{label}: synthetic {args.dtype} log_lik S={S} draws x N={n_local} observations per GPU, "
                         f"PSIS-LOO reff=1 (M={M}), device-resident, obs-sharded",
@@ -305,9 +319,14 @@ def main():
         done, t_cpu = 0, 0.0
         worst = {"khat": 0.0, "loo_i": 0.0, "lppd_i": 0.0}
         cap = min(n_local, 262144)
-        full = eng.psis_loo(ll[:cap], M, "psis", 1.0, good_k)
+        # the pass that was timed, once more with its pointwise outputs kept: the same launches on the same matrix, so its
+        # aggregates must equal the timed loop's bit for bit -- the rows checked against the oracle below are then rows of
+        # the very computation that was timed
+        full = eng.psis_loo(ll, M, "psis", 1.0, good_k)
         torch.cuda.synchronize()
-        gk, gl, gp = (full[k].cpu().numpy() for k in ("diag", "loo_i", "lppd_i"))
+        checked_agg = full["agg"].cpu().numpy()
+        same_pass = bool(world > 1 or np.array_equal(checked_agg, agg))
+        gk, gl, gp = (full[k][:cap].cpu().numpy() for k in ("diag", "loo_i", "lppd_i"))
         while t_cpu < args.cpu_seconds and done + chunk <= cap:
             rows = ll[done:done + chunk].cpu().numpy().astype(np.float64)
             c0 = time.perf_counter()
@@ -330,7 +349,8 @@ def main():
             "note": "oracle loop, >= reference speed: np.sort where the reference argsorts, no make_ufunc wrapper "
                     "(1.7x the real reference loop on identical rows in the build container, outputs bit-identical)",
         }
-        out["parity"] = {"rows": done, "max_rel_err": worst, "tolerance": 1e-6}
+        out["parity"] = {"rows": done, "max_rel_err": worst, "tolerance": 1e-6,
+                         "checked_pass_equals_timed_pass": same_pass if world == 1 else None}
         # second, clearly labelled CPU line: whole-matrix NumPy calls instead of the loop
         vrows = min(max(64, 2048 * 4000 // S), cap)
         host = ll[:vrows].cpu().numpy().astype(np.float64)

@@ -24,9 +24,12 @@
  *   - threads and streams: an engine is bound to one device and owns ONE workspace.  Every entry point that takes an
  *     engine holds the engine's mutex for the whole call, so concurrent calls from several threads are safe (they run one
  *     after the other); different engines are independent (no hidden global state).  PLA_DEVICE calls only ENQUEUE work
- *     that uses the workspace: issue them on ONE stream per engine (or order the streams yourself) -- two streams running
- *     passes of the same engine side by side would share its scratch buffers.  Growing the workspace frees the old buffers
- *     with hipFree, which waits for the device, so launches already enqueued are never left with dangling pointers.
+ *     that uses the workspace; the engine orders that work ACROSS STREAMS itself: every call records an event behind what
+ *     it enqueued, and a call on another stream first makes its stream wait for the previous call's event -- two streams
+ *     never run passes of one engine side by side, whatever the caller does (calls on one stream are ordered anyway).
+ *     For passes that should overlap use one engine per stream.  Inside a stream capture no event is waited for or
+ *     recorded: order captured work yourself.  Growing the workspace frees the old buffers with hipFree, which waits for
+ *     the device, so launches already enqueued are never left with dangling pointers.
  *   - HIP graphs: a captured PLA_DEVICE call holds raw workspace pointers.  Size the workspace first (one eager call
  *     of the largest shape and tail count to be replayed), then pla_engine_set_frozen(eng, 1): from then on a call that
  *     would have to reallocate returns PLA_ERR_FROZEN instead of invalidating the graph.  The per-tail-count quantile
@@ -41,7 +44,7 @@
 extern "C" {
 #endif
 
-#define PLA_ABI_VERSION 3
+#define PLA_ABI_VERSION 4
 
 /* status codes */
 #define PLA_OK 0
@@ -231,6 +234,19 @@ int pla_engine_first_kernel_ms(pla_engine *eng, double *total_ms, int64_t *launc
  * fit_rows_stream_kernel beside it + ..."): for benchmark records, so that what a roofline line names is what ran.
  * Copies at most cap - 1 characters and a terminating 0 into buf. */
 int pla_engine_last_kernels(pla_engine *eng, char *buf, int cap);
+
+/* Run-time switches of the library that are SET in this process's environment, as "NAME=value NAME=value" ("" when none is):
+ * for benchmark records.  The shipped library reads PLA_PIPE, PLA_STREAM_PATIENCE_US, PLA_FORCE_PATH, PLA_INGEST_TRANSPOSE and
+ * PLA_INGEST_BLOCK_MB -- path selectors, every setting of which computes the same results (csrc/pla_launch.h); builds with
+ * -DPLA_EXPERIMENT read more (ablation, grids, priorities), and the text then starts with "EXPERIMENT-BUILD".
+ * Copies at most cap - 1 characters and a terminating 0 into buf. */
+int pla_env_overrides(char *buf, int cap);
+
+/* Streamed PSIS-LOO passes (the fit kernel running beside the sweep): *gave_up = how many passes since the last call the fit
+ * kernel stopped waiting for the sweep (the two were not run side by side: a serialising profiler, a co-tenant holding the
+ * CUs) and left the rest to the plain fit kernel behind it -- correct, but the pass then costs up to 20 ms more, which a
+ * benchmark record should show.  Synchronises the device. */
+int pla_engine_stream_stats(pla_engine *eng, int64_t *gave_up);
 
 /*
  * Observation-sharded runs (loo.py:326-342 across devices): every device reduces its own block of

@@ -12,7 +12,7 @@ PLA_PSIS, PLA_SIS, PLA_TIS = 0, 1, 2
 METHOD_CODES = {"psis": PLA_PSIS, "sis": PLA_SIS, "tis": PLA_TIS}
 AGG_N, AGG_SUM_LOO, AGG_M2_LOO, AGG_SUM_LPPD, AGG_N_HIGH, AGG_N_NONFINITE, AGG_MIN_DIAG, AGG_N_SLOW = range(8)
 AGG_COUNT = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol declared in include/pyloo_amd.h
 SYMBOLS = (
@@ -21,6 +21,7 @@ SYMBOLS = (
     "pla_psis_loo_rows", "pla_waic_rows", "pla_e_loo", "pla_e_loo_quantiles",
     "pla_engine_set_frozen", "pla_engine_set_timing", "pla_engine_kernel_ms", "pla_engine_first_kernel_ms", "pla_fill_synthetic",
     "pla_engine_last_kernels", "pla_aggregate_pack", "pla_aggregate_merge", "pla_fill_synthetic_chains",
+    "pla_env_overrides", "pla_engine_stream_stats",
 )
 
 
@@ -81,6 +82,8 @@ def load_library():
     lib.pla_engine_last_kernels.argtypes = [vp, C.c_char_p, ci]
     lib.pla_aggregate_pack.argtypes = [vp, vp, ci, ci, vp, vp]
     lib.pla_aggregate_merge.argtypes = [vp, vp, ci, vp, vp]
+    lib.pla_env_overrides.argtypes = [C.c_char_p, ci]
+    lib.pla_engine_stream_stats.argtypes = [vp, C.POINTER(i64)]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError if the header and the library disagree
         if name != "pla_last_error":
@@ -94,6 +97,13 @@ def load_library():
 def check(code):
     if code != 0:
         raise EngineError(code, load_library().pla_last_error().decode("utf-8", "replace"))
+
+
+def env_overrides():
+    """Run-time switches of the library that are set in the environment ("" when none is): ``pla_env_overrides``."""
+    buf = C.create_string_buffer(1024)
+    check(load_library().pla_env_overrides(buf, 1024))
+    return buf.value.decode("utf-8", "replace")
 
 
 def device_count():

@@ -12,7 +12,7 @@
 #include <vector>
 
 #include "../../include/pyloo_amd.h"
-#include "pla_kernels.h"
+#include "pla_launch.h"
 
 namespace {
 
@@ -50,7 +50,7 @@ struct pla_engine {
   // frozen: the workspace may be referenced by a captured HIP graph; a call that would have to reallocate any of
   // it returns PLA_ERR_FROZEN instead (pla_engine_set_frozen)
   bool frozen = false;
-  unsigned long long* counters = nullptr;  // [16] device: [0] rows on the slow list, [1] running total, [2..3] clock probe, [4] group counter of the tile kernel (back to back), [8..15] reasons (profiling builds)
+  unsigned long long* counters = nullptr;  // [pla::kCountersTotal] device (layout: pla_launch.h): [0..15] per call, [16..] engine statistics
   double* d_red = nullptr;                 // reduction partials
   // staging for PLA_HOST callers (grown on demand)
   void* d_in = nullptr;
@@ -96,6 +96,11 @@ struct pla_engine {
   hipEvent_t pipe_t0[kPipeTimed] = {}, pipe_t1[kPipeTimed] = {};
   int pipe_timed = 0;
   std::string last_kernels;  // pla_engine_last_kernels
+  // ordering of the calls ACROSS streams: every call that enqueues work on the workspace records `order_event` behind it, and a
+  // call on another stream makes that stream wait for it first (EngineCall)
+  hipEvent_t order_event = nullptr;
+  hipStream_t order_stream = nullptr;
+  bool order_valid = false;
 };
 
 namespace {
@@ -170,11 +175,33 @@ int ensure_l1_table(pla_engine* e, int64_t M, hipStream_t s, const double** out)
   return PLA_OK;
 }
 
-// every entry point: serialise on the engine and publish its frozen flag to grow()
+// every entry point: serialise on the engine and publish its frozen flag to grow().  With a stream: the call enqueues work that
+// uses the engine's workspace -- it is ordered behind the previous such call when that one went to ANOTHER stream (one event
+// per engine, recorded at the end of every call; nothing inside a stream capture, whose order is the caller's)
 struct EngineCall {
   std::lock_guard<std::mutex> lock;
-  explicit EngineCall(pla_engine* e) : lock(e->mu) { g_frozen = e->frozen; }
-  ~EngineCall() { g_frozen = false; }
+  pla_engine* e;
+  hipStream_t s;
+  bool ordered;
+  explicit EngineCall(pla_engine* e_) : lock(e_->mu), e(e_), s(nullptr), ordered(false) { g_frozen = e->frozen; }
+  EngineCall(pla_engine* e_, hipStream_t s_) : lock(e_->mu), e(e_), s(s_), ordered(false) {
+    g_frozen = e->frozen;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipSetDevice(e->device) != hipSuccess || !e->order_event) return;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      return;
+    }
+    ordered = true;
+    if (e->order_valid && e->order_stream != s) (void)hipStreamWaitEvent(s, e->order_event, 0);
+  }
+  ~EngineCall() {
+    if (ordered && hipEventRecord(e->order_event, s) == hipSuccess) {
+      e->order_stream = s;
+      e->order_valid = true;
+    }
+    g_frozen = false;
+  }
 };
 
 struct TimedLaunch {  // brackets the main kernel with events when timing is on
@@ -270,9 +297,10 @@ int pla_engine_create(int device, pla_engine** out) {
   pla_engine* e = new (std::nothrow) pla_engine();
   if (!e) return fail(PLA_ERR_NOMEM, "out of host memory");
   e->device = device;
-  hipError_t he = hipMalloc((void**)&e->counters, 16 * sizeof(unsigned long long));
+  hipError_t he = hipMalloc((void**)&e->counters, pla::kCountersTotal * sizeof(unsigned long long));
   if (he == hipSuccess) he = hipMalloc((void**)&e->d_red, (size_t)pla::reduce_workspace_doubles() * sizeof(double));
-  if (he == hipSuccess) he = hipMemset(e->counters, 0, 16 * sizeof(unsigned long long));
+  if (he == hipSuccess) he = hipMemset(e->counters, 0, pla::kCountersTotal * sizeof(unsigned long long));
+  if (he == hipSuccess) he = hipEventCreateWithFlags(&e->order_event, hipEventDisableTiming);
   for (int i = 0; i < pla_engine::kTimingRing && he == hipSuccess; ++i) {
     he = hipEventCreate(&e->ev0[i]);
     if (he == hipSuccess) he = hipEventCreate(&e->ev1[i]);
@@ -306,6 +334,7 @@ int pla_engine_destroy(pla_engine* e) {
     if (e->ev1[i]) (void)hipEventDestroy(e->ev1[i]);
     if (e->evm[i]) (void)hipEventDestroy(e->evm[i]);
   }
+  if (e->order_event) (void)hipEventDestroy(e->order_event);
   if (e->pipe_first) (void)hipStreamDestroy(e->pipe_first);
   if (e->pipe_second) (void)hipStreamDestroy(e->pipe_second);
   if (e->d_sync) (void)hipFree(e->d_sync);
@@ -372,10 +401,44 @@ int pla_engine_last_kernels(pla_engine* eng, char* buf, int cap) {
   return PLA_OK;
 }
 
+int pla_env_overrides(char* buf, int cap) {
+  if (!buf || cap < 1) return fail(PLA_ERR_ARG, "buffer is NULL");
+  static const char* const kAlways[] = {"PLA_PIPE", "PLA_STREAM_PATIENCE_US", "PLA_FORCE_PATH", "PLA_INGEST_TRANSPOSE", "PLA_INGEST_BLOCK_MB"};
+  static const char* const kExperiment[] = {"PLA_DEBUG_SKIP", "PLA_FUSED", "PLA_SKIP_FIT", "PLA_NO_THRESHOLD_CHECK", "PLA_NO_RETRY", "PLA_NO_TILE",
+                                            "PLA_TILE_GRID", "PLA_FIT_GRID", "PLA_FIT_HELPERS", "PLA_WAVE_PRIO", "PLA_COL_BLOCK",
+                                            "PLA_PRINT_REASONS", "PLA_PRINT_CLOCK"};
+  std::string out = pla::kExperiment ? "EXPERIMENT-BUILD" : "";
+  const auto add = [&](const char* name) {
+    const char* v = getenv(name);
+    if (!v) return;
+    if (!out.empty()) out += " ";
+    out += name;
+    out += "=";
+    out += v;
+  };
+  for (const char* n : kAlways) add(n);
+  if (pla::kExperiment)
+    for (const char* n : kExperiment) add(n);
+  snprintf(buf, (size_t)cap, "%s", out.c_str());
+  return PLA_OK;
+}
+
+int pla_engine_stream_stats(pla_engine* eng, int64_t* gave_up) {
+  if (!eng) return fail(PLA_ERR_ARG, "engine is NULL");
+  EngineCall call(eng);
+  PLA_HIP(hipSetDevice(eng->device));
+  PLA_HIP(hipDeviceSynchronize());
+  unsigned long long h = 0;
+  PLA_HIP(hipMemcpy(&h, eng->counters + pla::kCounterGaveUp, sizeof(h), hipMemcpyDeviceToHost));
+  PLA_HIP(hipMemset(eng->counters + pla::kCounterGaveUp, 0, sizeof(h)));
+  if (gave_up) *gave_up = (int64_t)h;
+  return PLA_OK;
+}
+
 int pla_aggregate_pack(pla_engine* eng, const double* agg, int rank, int world, double* table, void* stream) {
   if (!eng || !agg || !table) return fail(PLA_ERR_ARG, "engine / agg / table is NULL");
   if (world < 1 || rank < 0 || rank >= world) return fail(PLA_ERR_ARG, "need 0 <= rank < world");
-  EngineCall call(eng);
+  EngineCall call(eng, (hipStream_t)stream);
   PLA_HIP(hipSetDevice(eng->device));
   PLA_HIP(pla::launch_aggregate_pack(agg, rank, world, table, (hipStream_t)stream));
   return PLA_OK;
@@ -384,7 +447,7 @@ int pla_aggregate_pack(pla_engine* eng, const double* agg, int rank, int world, 
 int pla_aggregate_merge(pla_engine* eng, const double* table, int world, double* out, void* stream) {
   if (!eng || !table || !out) return fail(PLA_ERR_ARG, "engine / table / out is NULL");
   if (world < 1) return fail(PLA_ERR_ARG, "world < 1");
-  EngineCall call(eng);
+  EngineCall call(eng, (hipStream_t)stream);
   PLA_HIP(hipSetDevice(eng->device));
   PLA_HIP(pla::launch_aggregate_merge(table, world, out, (hipStream_t)stream));
   return PLA_OK;
@@ -396,7 +459,7 @@ int pla_reduce_pointwise(pla_engine* eng, const double* diag, const double* loo_
   if (!agg) return fail(PLA_ERR_ARG, "agg is NULL");
   if (n_obs < 0) return fail(PLA_ERR_ARG, "n_obs < 0");
   if (mem_space != PLA_HOST && mem_space != PLA_DEVICE) return fail(PLA_ERR_ARG, "bad mem_space");
-  EngineCall call(eng);
+  EngineCall call(eng, (hipStream_t)stream);
   PLA_HIP(hipSetDevice(eng->device));
   hipStream_t s = (hipStream_t)stream;
   if (mem_space == PLA_DEVICE) {
@@ -500,15 +563,15 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
     rc = check_rows(row_index, n_obs, n_src, mem_space);
     if (rc) return rc;
   }
-  EngineCall call(eng);
+  EngineCall call(eng, (hipStream_t)stream);
   PLA_HIP(hipSetDevice(eng->device));
   hipStream_t s = (hipStream_t)stream;
   const size_t esz = dtype == PLA_F64 ? 8 : 4;
   const bool ingest = obs_fastest_device(mem_space, row_index, n_src, n_draws, stride_obs, stride_draw);
   // observations-fastest PSIS-LOO: the lane-per-observation kernels read the matrix as it lies (pla_col.h); PLA_INGEST_TRANSPOSE=1
   // keeps round 1's transposing ingestion (A/B runs), which also serves the shapes the column kernels do not take
-  static const int64_t kColBlock = [] {  // observations per launch: 8 KB of candidate lists each (PLA_COL_BLOCK: A/B runs)
-    const char* e = getenv("PLA_COL_BLOCK");
+  static const int64_t kColBlock = [] {  // observations per launch: 8 KB of candidate lists each (PLA_COL_BLOCK: A/B runs, experiment builds only)
+    const char* e = pla::exp_str("PLA_COL_BLOCK");
     const int64_t v = e ? atoll(e) : 0;
     // (at most 262 144: the lists of one launch are addressed with 32-bit byte offsets, 8 KB per observation)
     return v >= 256 ? (v <= 262144 ? v : (int64_t)262144) : (int64_t)262144;
@@ -595,7 +658,7 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
   if (!use_tile) tile_stream = false;
   if (use_tile && !tile_stream) (void)pla::tile_supported(dtype, (int)n_draws, (int)tail_count, stride_draw, false, &tile_ks);  // (the longer lists' threshold)
   // [1]: rows left to the general kernel (a streamed pass zeroes the counters together with its flags: one command less)
-  if (!pipeline && !tile_stream) PLA_HIP(hipMemsetAsync(eng->counters, 0, 16 * sizeof(unsigned long long), s));
+  if (!pipeline && !tile_stream) PLA_HIP(hipMemsetAsync(eng->counters, 0, pla::kCountersPerCall * sizeof(unsigned long long), s));
 
   if (mem_space == PLA_DEVICE) {
     // agg needs the pointwise loo_i: use the caller's vectors, or the engine scratch
@@ -725,14 +788,14 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
       }
     }
 #if defined(PLA_WAVE_ABLATE) && PLA_WAVE_ABLATE
-    if (getenv("PLA_PRINT_REASONS")) {  // profiling build only: why rows left the fast path
+    if (pla::exp_str("PLA_PRINT_REASONS")) {  // profiling build only: why rows left the fast path
       unsigned long long h[16];
       PLA_HIP(hipStreamSynchronize(s));
       PLA_HIP(hipMemcpy(h, eng->counters, sizeof(h), hipMemcpyDeviceToHost));
       fprintf(stderr, "[pla] slow rows by reason: range %llu, threshold search %llu, t1>=0 %llu, pads %llu, too few candidates %llu, "
                       "too many %llu, other %llu, selection/fit %llu\n", h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
     }
-    if (getenv("PLA_PRINT_CLOCK")) {  // profiling build only: core clock seen by one wave of the fast kernel
+    if (pla::exp_str("PLA_PRINT_CLOCK")) {  // profiling build only: core clock seen by one wave of the fast kernel
       unsigned long long h[4];
       PLA_HIP(hipStreamSynchronize(s));
       PLA_HIP(hipMemcpy(h, eng->counters, sizeof(h), hipMemcpyDeviceToHost));
@@ -826,7 +889,7 @@ int pla_importance_weights(pla_engine* eng, const void* logw, int dtype, int64_t
   int rc = check_common(eng, logw, dtype, n_obs, n_draws, stride_obs, stride_draw, method, tail_count, mem_space);
   if (rc) return rc;
   if (n_obs > 0 && !lw_out) return fail(PLA_ERR_ARG, "lw_out is NULL");
-  EngineCall call(eng);
+  EngineCall call(eng, (hipStream_t)stream);
   PLA_HIP(hipSetDevice(eng->device));
   hipStream_t s = (hipStream_t)stream;
   const size_t esz = dtype == PLA_F64 ? 8 : 4;
@@ -839,7 +902,7 @@ int pla_importance_weights(pla_engine* eng, const void* logw, int dtype, int64_t
   p.tail_cap = pow2_at_least(p.tail_count);
   p.scale_value = 1.0;
   p.counters = eng->counters;
-  PLA_HIP(hipMemsetAsync(eng->counters, 0, 16 * sizeof(unsigned long long), s));
+  PLA_HIP(hipMemsetAsync(eng->counters, 0, pla::kCountersPerCall * sizeof(unsigned long long), s));
   if (n_obs > 0) {  // workspace of the fast path (rows it declines, quantile tables)
     rc = grow(&eng->d_slow, &eng->d_slow_bytes, (size_t)n_obs * sizeof(unsigned));
     if (rc) return rc;
@@ -933,11 +996,11 @@ static int waic_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_src, 
     rc = check_rows(row_index, n_obs, n_src, mem_space);
     if (rc) return rc;
   }
-  EngineCall call(eng);
+  EngineCall call(eng, (hipStream_t)stream);
   PLA_HIP(hipSetDevice(eng->device));
   hipStream_t s = (hipStream_t)stream;
   const size_t esz = dtype == PLA_F64 ? 8 : 4;
-  PLA_HIP(hipMemsetAsync(eng->counters, 0, 16 * sizeof(unsigned long long), s));  // [1]: replaced entries
+  PLA_HIP(hipMemsetAsync(eng->counters, 0, pla::kCountersPerCall * sizeof(unsigned long long), s));  // [1]: replaced entries
 
   if (mem_space == PLA_DEVICE) {
     double *dl = lppd_i, *dv = var_i, *dw = waic_i;
@@ -1055,7 +1118,7 @@ int pla_e_loo(pla_engine* eng, const void* x, const void* log_weights, const voi
   if (stride_draw <= 0 || stride_obs < 0) return fail(PLA_ERR_ARG, "bad strides");
   if (tail_len < 5) return fail(PLA_ERR_ARG, "tail_len must be at least 5");  // e_loo.py:298-299
   if (n_obs == 0) return PLA_OK;
-  EngineCall call(eng);
+  EngineCall call(eng, (hipStream_t)stream);
   PLA_HIP(hipSetDevice(eng->device));
   hipStream_t s = (hipStream_t)stream;
   // (row list of the one-pass wave kernel: the rows it leaves to the general one)
@@ -1114,7 +1177,7 @@ int pla_e_loo_quantiles(pla_engine* eng, const void* x, const void* log_weights,
   for (int64_t i = 0; i < n_probs; ++i)
     if (!(probs[i] > 0.0 && probs[i] < 1.0)) return fail(PLA_ERR_ARG, "probs must be between 0 and 1");  // e_loo.py:158-159
   if (n_obs == 0 || n_probs == 0) return PLA_OK;
-  EngineCall call(eng);
+  EngineCall call(eng, (hipStream_t)stream);
   PLA_HIP(hipSetDevice(eng->device));
   hipStream_t s = (hipStream_t)stream;
   int rc = grow(&eng->d_probs, &eng->d_probs_bytes, (size_t)n_probs * sizeof(double));

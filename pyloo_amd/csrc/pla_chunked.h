@@ -273,7 +273,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
       wave_select_split<SM, TB, (SM::Caps::kMaxTail + 63) / 64>(F, sm, tb, r, lane, M, m, mn, s1, s2, ncand, k1, sh, magic, c256, slow,
                                                                 CandInLds<SM>{sm});
     } else {
-      wave_back<T, VEC, LW, SM, TB, false, LW>(P, sm, tb, r, v, lane, S, M, mestM, logS, dbgs, m, mn, R, delta, s1, s2, ncand, k1,
+      wave_back<T, VEC, LW, SM, TB, LW>(P, sm, tb, r, v, lane, S, M, mestM, logS, dbgs, m, mn, R, delta, s1, s2, ncand, k1,
                                                sh, magic, c256, nvl / kWave, nvl % kWave, slow, khat, loo, lppd);
     }
   }

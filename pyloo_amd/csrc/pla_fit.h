@@ -67,15 +67,19 @@ struct FitParams {
   unsigned slow_base = 0;  // added to the row numbers written to slow_list
   int ws_sstride = 8;      // doubles per observation in ws_s
   // streamed pass (fit_rows_stream_kernel): chunks of kQueueChunk observations are taken from `take` in order, each once
-  // `done[c]` is set by the wave kernel running beside this one; `fitted[c]` is set behind the chunk's outputs.  Polling gives
-  // up after `patience` looks (the two kernels were not run side by side after all): `gave_up` is then set and the chunks not
-  // fitted are left to the plain fit kernel, which the launcher always runs behind both (fit_rows_kernel with `fitted`: it only
-  // looks at chunks whose flag is clear, i.e. at nothing in the usual case).
+  // `done[c]` is set by the wave kernel running beside this one; `fitted[c]` is set behind the chunk's outputs.  Waiting is
+  // bounded in TIME (s_memrealtime, 100 MHz): when a chunk's flag has not come for `patience` ticks the producer's row queue
+  // (`producer`) is looked at, and if that has not moved either -- the two kernels are not running side by side after all, e.g.
+  // under a profiler that serialises them -- `gave_up` is set and the chunks not fitted are left to the plain fit kernel, which
+  // the launcher always runs behind both (fit_rows_kernel with `fitted`: it only looks at chunks whose flag is clear, i.e. at
+  // nothing in the usual case).  `patience_start` applies while the producer has not taken a single row yet.
   const unsigned* done = nullptr;
   unsigned* take = nullptr;
   unsigned* fitted = nullptr;
   unsigned* gave_up = nullptr;
-  unsigned patience = 0;
+  const unsigned* producer = nullptr;
+  unsigned patience = 0, patience_start = 0;
+  unsigned long long* gave_up_total = nullptr;  // engine statistics: passes in which the streamed fit gave up (plain fit kernel, leftovers)
 };
 
 // 16 bytes of the hand-over.  STREAM: an agent-scope (sc1) load straight from memory -- the bytes were written, by the kernel
@@ -121,6 +125,7 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
   if constexpr (!STREAM) {
     // behind a streamed pass, which fitted everything unless it gave up waiting: nothing to do, not even the tables
     if (Q.fitted && Q.gave_up && *Q.gave_up == 0u) return;
+    if (Q.fitted && Q.gave_up_total && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(Q.gave_up_total, 1ull);
   }
   __shared__ int s_chunk[2];
   constexpr int kFitWaves = W;  // (shadows the default: everything below is per instantiation)
@@ -198,6 +203,7 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     // are used instead of being hoisted above the loop, where a dozen of them sit on the register budget of the slim variant)
     int t = t_lane;
     if constexpr (DYN) asm volatile("" : "+v"(t));
+    PLA_PHASE(20);
     const int64_t r0 = grp * 4 + rho;
     const bool inrange = r0 < Q.n_obs;
     const int64_t r = inrange ? r0 : Q.n_obs - 1;
@@ -218,6 +224,7 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     double yq, yn;
     if constexpr (kFitSorts) {
       constexpr int K = 4 * NQ;
+    PLA_PHASE(21);
       // interleaved (as loaded) -> blocked, through this wave's LDS scratch (the coefficient area: written later)
       double* ys = ys_base + rho * (64 * NQ);
 #pragma unroll
@@ -228,6 +235,7 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
         yv[i] = *reinterpret_cast<const double2*>(ys + K * t + 2 * i);
         if (!fit) yv[i] = make_double2(0.0, 0.0);  // (nothing was handed over: whatever the buffer held must not reach the sort)
       }
+    PLA_PHASE(22);
       // descending odd-even transposition sort of the row's 16 K values: yb(i) = rank K t + i
       const auto yb = [&](int i) -> double& { return (i & 1) ? yv[i >> 1].y : yv[i >> 1].x; };
       const auto ce = [&](double& hi, double& lo) {
@@ -258,6 +266,7 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
       for (int it = 0; it < 4; ++it) sort_round();
 #pragma unroll 1
       for (int it = 0; it < 8 * K && unsorted(); ++it) sort_round();
+    PLA_PHASE(23);
       // y = e^x - e^xcut (psis.py:147) of the sorted tail; ranks from n on are padding (x = xcut): y = 0 exactly
 #pragma unroll
       for (int i = 0; i < 2 * NQ; ++i) yv[i] = make_double2(exp_tab(yv[i].x, tab) - e_cut, exp_tab(yv[i].y, tab) - e_cut);
@@ -271,6 +280,7 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
       yq = y[iq > 0 ? iq : 0];
       yn = y[n > 0 ? n - 1 : 0];
     }
+    PLA_PHASE(24);
     const double R = m - mn;
     const double nn = (double)n, rn = recip_fast(nn);
     bool bad = (30 + isqrt_i(n)) != mestM;  // (ties shortened the tail a lot: the host grid table does not apply)
@@ -280,6 +290,7 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
       const double fbig = fma(-fma(g_first, cb, db), yn, 1.0), fsmall = fma(-fma(g_last, cb, db), yn, 1.0);
       if (!((fbig < 0x1p30) && (fsmall > 0x1p-30))) bad = true;
     }
+    PLA_PHASE(25);
     // ---- quartic coefficients of this lane's quads --------------------------------------------------------
     // 1 - b_j y = (1 - y/yn) - g_j y/(3 yq) = u + g_j t with u >= 0, t <= 0 and every g_j < 0: the product over
     // four y is a quartic in g_j whose terms are all non-negative (no cancellation)
@@ -305,6 +316,7 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
 #endif
     }
     wave_sync();
+    PLA_PHASE(26);
     // ---- grid pass: three running products per lane over the 16 NQ quads of the observation -------------------
     double pm[G];
     int pe[G];
@@ -354,6 +366,7 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     }
 #endif
     wave_sync();  // (the next group's coefficients are written after these reads)
+    PLA_PHASE(27);
     // ---- profile likelihood, softmax weights, posterior mean of b (psis.py:190-201) --------------------------
     double ls[G], bb[G], lp[G];
     bool tiny[G];
@@ -421,6 +434,7 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     }
     const double sw = row_all(swl, op_sum), bw = row_all(bwl, op_sum);
     const double b_post = (sw > 0.0) ? div_fast(bw, sw) : 0.0;                                    // psis.py:198,201
+    PLA_PHASE(28);
     // ---- k_post = mean log1p(-b_post y) (psis.py:203) from the lane's own quads --------------------------------
     double km = 1.0;
     {
@@ -438,6 +452,7 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     const double k_post = (log_tab(kmr, lt) + (double)ke * kLn2) * rn;
     const double sigma = -k_post / b_post;                                                        // psis.py:205
     const double khat = (nn * k_post + 5.0) / (nn + 10.0);                                        // psis.py:206
+    PLA_PHASE(29);
     // ---- smoothed tail: sums of w'_j - e_j and w'_j / e_j (psis.py:150-158, 211-231) ---------------------------
     const bool smoothed = fit && isfinite(khat);
     // w_j = sigma/k (e^{z_j} - 1) + e_cut with z_j = -k log1p(-p_j); e^z - 1 by subtraction is accurate to 1e-16
@@ -489,6 +504,7 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
         pin();
       }
     }
+    PLA_PHASE(30);
     const double at = row_all(acc_t, op_sum), ar = row_all(acc_r, op_sum);
     // ---- outputs (loo.py:289,319-337 through the shortcuts of DESIGN.md section 4) --------------------------
     const double total = smoothed ? s1 + at : s1;
@@ -516,21 +532,29 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     // The chunks in order, each once the wave kernel has finished it.  One lane takes the next chunk number (a returning atomic:
     // issued before this chunk's arithmetic, used behind it), looks at its flag (agent-scope loads, a sleep in between) and
     // posts it in LDS; the workgroup barrier stands between that poll and every load of the chunk's bytes.
+    // false: gave up (see FitParams::patience)
+    const auto wait_for = [&](const int c) -> bool {
+      if (__hip_atomic_load(Q.done + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
+      unsigned long long mark = __builtin_amdgcn_s_memrealtime();
+      unsigned seen = __hip_atomic_load(Q.producer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (;;) {
+        __builtin_amdgcn_s_sleep(PLA_STREAM_SLEEP);
+        if (__hip_atomic_load(Q.done + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (now - mark > (unsigned long long)(seen ? Q.patience : Q.patience_start)) {
+          const unsigned q = __hip_atomic_load(Q.producer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (q == seen) {  // the producer's row queue stands still: it is not running beside this kernel
+            __hip_atomic_store(Q.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+          }
+          seen = q;
+          mark = now;
+        }
+      }
+    };
     if (tid == 0) {
       int c = (int)atomicAdd(Q.take, 1u);
-      if ((int64_t)c < nchunks) {
-        unsigned looks = 0;
-        while (__hip_atomic_load(Q.done + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-          if (++looks > Q.patience) {
-            __hip_atomic_store(Q.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            c = -1;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(PLA_STREAM_SLEEP);
-        }
-      } else {
-        c = -1;
-      }
+      if ((int64_t)c >= nchunks || !wait_for(c)) c = -1;
       s_chunk[0] = c;
     }
     int prev_chunk = -1;
@@ -547,19 +571,7 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
       const int64_t grp = (int64_t)c * (kQueueChunk / 4) + wv;
       if (grp < ngroups) fit_group(grp);  // (the last chunk may be short)
       if (tid == 0) {
-        if ((int64_t)nxt < nchunks) {
-          unsigned looks = 0;
-          while (__hip_atomic_load(Q.done + nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            if (++looks > Q.patience) {
-              __hip_atomic_store(Q.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              nxt = -1;
-              break;
-            }
-            __builtin_amdgcn_s_sleep(PLA_STREAM_SLEEP);
-          }
-        } else {
-          nxt = -1;
-        }
+        if ((int64_t)nxt >= nchunks || !wait_for(nxt)) nxt = -1;
         s_chunk[(trip + 1) & 1] = nxt;
       }
     }

@@ -538,14 +538,15 @@ __device__ __forceinline__ void lw_patch_tail(SM& sm, const TB& tb, T* orow, con
 
 // (DEFER, weights mode of the chunked kernel: the row is not in the registers, so nothing is stored here; `loo` returns
 // L = log(total) and `lppd` the smoothed tail length (0: nothing to patch) for lw_store_chunk / lw_patch_tail below)
-template <typename T, int VEC, bool LW, typename SM, typename TB, bool SPLIT = false, bool DEFER = false>
+// (the split pass never comes here: its selection is wave_select_split() below, the ONE producer of the hand-over's format)
+template <typename T, int VEC, bool LW, typename SM, typename TB, bool DEFER = false>
 __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB& tb, const int64_t r, T (&v)[kWaveSlots],
                                           const int lane, const int S, const int M, const int mestM, const double logS,
                                           const int dbgs, const double m, const double mn, const double R,
                                           const double lppd_shift, double s1, double s2, const unsigned ncand,
                                           const int k1, const int sh, const double magic, const double c256,
                                           const int qfull, const int qrem, bool& slow, double& khat, double& loo,
-                                          double& lppd, const FastParams* F = nullptr) {
+                                          double& lppd) {
   constexpr int NQ = kWaveSlots / VEC;
   constexpr int kSa = SM::Caps::kSa;
   const double INF = pinf();
@@ -650,56 +651,6 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
         }
       }
     }
-    if constexpr (SPLIT && kFitSorts) {
-      // ---- split pass: hand the tail over to the fit kernel (pla_fit.h: 16 lanes per observation) -----------------
-      // The candidates are grouped by bin, bins descending, and that is how they go: the fit kernel finishes the order
-      // inside its 16-lane rows with a few odd-even transposition passes (bins hold a handful of values), which costs a
-      // tenth of ranking them here with 64 lanes per observation.  Only the boundary bin is resolved now: it holds the
-      // cutoff x_(S-M) itself (psis.py:135-136) and decides which of its members belong to the tail (strictly above it,
-      // psis.py:139: ties at the cutoff leave the tail).
-      wave_sync();
-      PLA_PHASE(8);
-      const int na = C1 - nbnd;  // candidates in the bins above the boundary bin: all of them are in the tail
-      if (nbnd > kWave) {
-        slow = true;  // (more than 64 draws share the cutoff's bin: heavy ties)
-      } else {
-        const double xb = sm.sa[na + (lane < nbnd ? lane : 0)];
-        int gt = 0, ge = 0;
-        for (int j = 0; j < nbnd; ++j) {
-          const double xj = lane_value(xb, j);
-          gt += (xj > xb) ? 1 : 0;
-          ge += (xj >= xb) ? 1 : 0;
-        }
-        // the cutoff is the (M - na)-th largest (0-based) of the boundary bin: the value with gt <= M - na < ge
-        const int want = M - na;
-        const unsigned long long isc = __ballot(lane < nbnd && gt <= want && want < ge);
-        const int src = __ffsll((long long)isc) - 1;
-        const double xcut = lane_value(xb, src);
-        const int n = na + __builtin_amdgcn_readlane(gt, src);  // draws strictly above the cutoff
-        const double e_cut = exp_tab(xcut, tb.tab);
-        double s1_all, s2_all;
-        wave_all2<R_SUM>(s1, s2, s1_all, s2_all);
-        double* wy = F->ws_y + r * (int64_t)F->ws_stride;
-        if (n > 4) {
-          // y = e^x - e^xcut (psis.py:147) in the candidates' order (descending up to the order inside a bin), zeros from n
-          // up to the row stride; the boundary bin's tail members follow the higher bins
-          for (int j = lane; j < F->ws_stride; j += kWave) {
-            const double ej = exp_tab(sm.sa[j < na ? j : 0], tb.tab);
-            if (j < na || j >= n) wy[j] = j < na ? ej - e_cut : 0.0;
-          }
-          const bool mine = lane < nbnd && xb > xcut;
-          const unsigned long long mm = __ballot(mine);
-          const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
-          const double eb = exp_tab(xb, tb.tab);
-          if (mine) wy[na + (int)pos] = eb - e_cut;
-        }
-        if (lane == 0) {
-          double* ws = F->ws_s + r * 8;
-          ws[0] = m; ws[1] = mn; ws[2] = s1_all; ws[3] = s2_all; ws[4] = e_cut; ws[5] = (double)n;
-        }
-      }
-      return;
-    }
     if (lane < 4) sm.sa[C1 + lane] = -INF;  // sentinels for the 4-wide reads of the ranking loop
     wave_sync();
     PLA_PHASE(7);
@@ -739,24 +690,6 @@ __device__ __forceinline__ void wave_back(const RowsParams& P, SM& sm, const TB&
     const double e_cut = exp_tab(xcut, tb.tab);
     double acc_t = 0.0, acc_r = 0.0;  // (sum w' - sum e) and sum w'/e over the tail
     bool smoothed = false;
-    if constexpr (SPLIT) {
-      // ---- split pass: hand the tail over to the fit kernel (pla_fit.h: 16 lanes per observation) -----------------
-      double s1_all, s2_all;
-      wave_all2<R_SUM>(s1, s2, s1_all, s2_all);
-      double* wy = F->ws_y + r * (int64_t)F->ws_stride;
-      if (n > 4) {
-        // y ascending (psis.py:146-147), zeros from n up to the row stride
-        for (int j = lane; j < F->ws_stride; j += kWave) {
-          const double ej = exp_tab(sb[j < n ? n - 1 - j : 0], tb.tab);
-          wy[j] = j < n ? ej - e_cut : 0.0;
-        }
-      }
-      if (lane == 0) {
-        double* ws = F->ws_s + r * 8;
-        ws[0] = m; ws[1] = mn; ws[2] = s1_all; ws[3] = s2_all; ws[4] = e_cut; ws[5] = (double)n;
-      }
-      return;
-    }
     if (n > 4 && !(dbgs & 8)) {
       wave_sync();
       // y ascending (psis.py:146-147), stored with the pair sums / products the fit loop eats
@@ -1436,8 +1369,9 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
       wave_select_split<SM, TB, 4, CandInLds<SM>, SYNC>(F, sm, tb, r, lane, M, m, mn, s1, s2, ncand, k1, sh, magic, c256, slow,
                                                         CandInLds<SM>{sm}, dbgs);
     } else {
-      wave_back<T, VEC, LW, SM, TB, SPLIT>(P, sm, tb, r, v, lane, S, M, mestM, logS, dbgs, m, mn, R, 0.0, s1, s2, ncand, k1, sh,
-                                           magic, c256, qfull, qrem, slow, khat, loo, lppd, &F);
+      static_assert(!SPLIT, "split pass: LOO mode only, through wave_select_split");
+      wave_back<T, VEC, LW, SM, TB>(P, sm, tb, r, v, lane, S, M, mestM, logS, dbgs, m, mn, R, 0.0, s1, s2, ncand, k1, sh, magic, c256,
+                                    qfull, qrem, slow, khat, loo, lppd);
     }
   }
   // the next row starts streaming into the (now dead) row registers while the outputs are stored and

@@ -390,6 +390,13 @@ class Engine:
         check(self._lib.pla_engine_last_kernels(self._h, buf, 512))
         return buf.value.decode("utf-8", "replace")
 
+    def stream_gave_up(self):
+        """Streamed passes since the last call in which the fit kernel stopped waiting for the sweep (``pla_engine_stream_stats``;
+        synchronises the device).  0 in a healthy run."""
+        n = C.c_int64(0)
+        check(self._lib.pla_engine_stream_stats(self._h, C.byref(n)))
+        return int(n.value)
+
     def aggregate_pack(self, agg, rank, world, table):
         """``table`` (world x 8, this engine's device) = zeros except row ``rank`` = ``agg``: one kernel on the current stream."""
         check(self._lib.pla_aggregate_pack(self._h, C.c_void_p(agg.data_ptr()), int(rank), int(world), C.c_void_p(table.data_ptr()),

@@ -374,6 +374,10 @@ def loo_subsample(data, observations=100, loo_approximation="plpd", estimator="d
             raise ValueError(f"log_p and log_q must have the same length, got {len(log_p)} and {len(log_q)}")
         try:
             draw_index = importance_resample(log_p=log_p, log_q=log_q, method=resample_method, seed=seed)
+            if len(draw_index) != n_samples:
+                # the reference reshapes the resampled draws to the stacked shape (loo_subsample.py:348-356): any other length
+                # raises there and lands in the fallback below
+                raise ValueError(f"cannot reshape array of size {len(draw_index)} into shape ({n_samples},)")
             if len(draw_index) and (np.min(draw_index) < 0 or np.max(draw_index) >= n_samples):
                 raise IndexError(f"index {int(np.max(draw_index))} is out of bounds for axis 0 with size {n_samples}")
         except Exception as e:  # noqa: BLE001  (the reference's catch-all: loo_subsample.py:363-370)

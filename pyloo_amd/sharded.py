@@ -74,19 +74,22 @@ def merge_moment_rows_tensor(table):
     return out
 
 
-_TABLES = {}  # (device, world) -> (table, out): allocated once, so that a timed step allocates nothing
+_TABLES = {}  # (device, world, group) -> (table, out): allocated once, so that a timed step allocates nothing
 
 
 def all_reduce_aggregates_device(agg, engine, group=None):
     """The multi-GPU step of a timed loop: ``agg`` is this rank's aggregate vector on the GPU; the merged vector comes back
     as a CUDA tensor, identical on every rank.  One step is exactly: one pack kernel (``pla_aggregate_pack``: this rank's row
     of a preallocated ``world x 8`` table, the other rows zero), ONE all-reduce of that table (RCCL over xGMI) and one merge
-    kernel (``pla_aggregate_merge``); nothing synchronises with the host and nothing is allocated."""
+    kernel (``pla_aggregate_merge``); nothing synchronises with the host and nothing is allocated.
+
+    The returned tensor is the preallocated result buffer of (device, world, group): it is valid until the NEXT call with the
+    same three, which overwrites it -- ``.clone()`` it to keep a step's result beyond that."""
     import torch
     import torch.distributed as dist
 
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    key = (agg.device, world)
+    key = (agg.device, world, id(group) if group is not None else None)
     if key not in _TABLES:
         _TABLES[key] = (torch.zeros((world, AGG_COUNT), dtype=torch.float64, device=agg.device),
                         torch.zeros(AGG_COUNT, dtype=torch.float64, device=agg.device))

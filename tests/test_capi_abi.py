@@ -69,6 +69,37 @@ def test_argument_errors_are_status_codes(lib):
     assert lib.pla_last_error()
 
 
+def test_shipped_library_reads_only_the_path_selectors(lib, monkeypatch):
+    """the knobs that change timings or results (phase ablation, skipped fit, grids, priorities, the threshold
+    check) exist only in -DPLA_EXPERIMENT builds.  The shipped library names what it reads through pla_env_overrides -- the
+    five path selectors -- and the kernel sources ask for an environment variable in no other way."""
+    from pyloo_amd import _capi
+
+    for k in list(os.environ):
+        if k.startswith("PLA_"):
+            monkeypatch.delenv(k)
+    assert _capi.env_overrides() == ""
+    for k in ("PLA_SKIP_FIT", "PLA_DEBUG_SKIP", "PLA_NO_THRESHOLD_CHECK", "PLA_FUSED", "PLA_WAVE_PRIO", "PLA_FIT_GRID", "PLA_NO_TILE"):
+        monkeypatch.setenv(k, "1")
+    assert _capi.env_overrides() == ""  # not an experiment build: these are not read, and not reported
+    monkeypatch.setenv("PLA_PIPE", "0")
+    monkeypatch.setenv("PLA_FORCE_PATH", "1")
+    assert _capi.env_overrides() == "PLA_PIPE=0 PLA_FORCE_PATH=1"
+    assert lib.pla_env_overrides(None, 0) == -1 and lib.pla_engine_stream_stats(None, None) == -1
+    # every getenv of the library: the one helper behind env_flag / exp_flag (pla_launch.h) and the selectors of pla_capi.hip
+    allowed = {"PLA_PIPE", "PLA_STREAM_PATIENCE_US", "PLA_FORCE_PATH", "PLA_INGEST_TRANSPOSE", "PLA_INGEST_BLOCK_MB"}
+    csrc = os.path.join(ROOT, "pyloo_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        text = open(os.path.join(csrc, f)).read()
+        text = re.sub(r"//[^\n]*", "", text)
+        for name in re.findall(r'getenv\("(PLA_[A-Z_]+)"\)', text) + re.findall(r'env_flag\("(PLA_[A-Z_]+)"\)', text):
+            assert name in allowed, (f, name)
+        for name in re.findall(r'exp_(?:flag|str)\("(PLA_[A-Z_]+)"\)', text):
+            assert name not in allowed, (f, name)
+    text = open(os.path.join(csrc, "pla_launch.h")).read()
+    assert "constexpr int exp_flag(const char*) { return 0; }" in text and "#if defined(PLA_EXPERIMENT)" in text
+
+
 def test_no_cpu_fallback_without_gpu():
     import pyloo_amd
     from pyloo_amd import _capi

@@ -107,14 +107,19 @@ def test_streamed_pass_equals_the_kernels_back_to_back(eng, n_obs, monkeypatch):
             assert bool(same.all()), (k, int((~same).sum()))
             assert torch.equal(ref_other[k], got_other[k]), ("other matrix", k)
     del other
-    # the fit kernel gives up waiting after ONE look at a chunk's flag (what a profiler that serialises the two kernels the
-    # wrong way round would cause, after seconds): whatever it left is fitted by the plain fit kernel behind it -- same bits
-    monkeypatch.setenv("PLA_STREAM_PATIENCE", "1")
+    assert eng.stream_gave_up() == 0  # (no streamed pass so far had to fall back)
+    # the fit kernel gives up waiting after ONE microsecond without its chunk (what a profiler that serialises the two kernels
+    # the wrong way round causes, after its 2 / 20 ms): whatever it left is fitted by the plain fit kernel behind it -- same
+    # bits -- and the engine's statistics say that it happened
+    monkeypatch.setenv("PLA_STREAM_PATIENCE_US", "1")
     got = run("1")
-    monkeypatch.delenv("PLA_STREAM_PATIENCE")
+    monkeypatch.delenv("PLA_STREAM_PATIENCE_US")
     for k in ref:
         same = (ref[k] == got[k]) | (torch.isnan(ref[k]) & torch.isnan(got[k]))
         assert bool(same.all()), ("gave up", k, int((~same).sum()))
+    if n_obs >= 1000:  # (with five rows the sweep may be over before the fit kernel looks at all)
+        assert eng.stream_gave_up() >= 1
+    assert eng.stream_gave_up() == 0  # (read and reset)
     # and against the oracle (a sample)
     idx = np.unique(np.linspace(0, n_obs - 1, 40).astype(np.int64))
     rows = t[torch.from_numpy(idx).to(t.device)].cpu().numpy()
@@ -122,6 +127,44 @@ def test_streamed_pass_equals_the_kernels_back_to_back(eng, n_obs, monkeypatch):
     close(got["diag"].cpu().numpy()[idx], want["khat"], what="khat")
     close(got["loo_i"].cpu().numpy()[idx], want["loo_i"], what="loo_i")
     del t
+    torch.cuda.empty_cache()
+
+
+def test_calls_on_two_streams_of_one_engine_do_not_share_the_workspace(eng):
+    """re-entrancy per (device, stream).  One engine = one workspace (hand-over buffer, flags, row
+    lists), so the engine orders its calls across streams itself: every call records an event behind its work and a call on
+    another stream waits for it.  Two matrices, passes enqueued alternately on two streams with nothing in between on the
+    host: every result equals the one-stream result bit for bit (before: whichever pass came second wrote into the hand-over
+    the first was still reading)."""
+    import torch
+
+    S, n = 4000, 150_001
+    M = orc.tail_count(S, 1.0)
+    mats = []
+    for seed in (0x5EED0011, 0x5EED0012):
+        t = torch.empty((n, S), dtype=torch.float64, device="cuda")
+        eng.fill_synthetic(t, seed=seed, k_lo=0.05, k_hi=0.8)
+        mats.append(t)
+    torch.cuda.synchronize()
+    ref = []
+    for t in mats:
+        r = eng.psis_loo(t, M, "psis", 1.0, 0.7)
+        torch.cuda.synchronize()
+        ref.append({k: r[k].clone() for k in ("diag", "loo_i", "lppd_i", "agg")})
+    assert not torch.equal(ref[0]["loo_i"], ref[1]["loo_i"])
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = []
+    for rep in range(3):
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                got.append((i, eng.psis_loo(mats[i], M, "psis", 1.0, 0.7)))
+            with torch.cuda.stream(streams[1 - i]):  # and the other layout's kernels of the same workspace on the other stream
+                got.append((1 - i, eng.psis_loo(mats[1 - i], M, "psis", 1.0, 0.7)))
+    torch.cuda.synchronize()
+    for i, r in got:
+        for k in ref[i]:
+            assert torch.equal(ref[i][k], r[k]), (i, k)
+    del mats, got, ref
     torch.cuda.empty_cache()
 
 
@@ -222,6 +265,29 @@ def test_bench_launches_two_ranks(eng):
     assert "wave_loo_kernel" in out["roofline"]["kernels"]
     assert out["value"] > 0 and abs(out["value"] - 2 * n_local * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
     t = torch.empty((2 * n_local, S), dtype=torch.float64, device="cuda")
+    eng.fill_synthetic(t, seed=0x5EED0003)  # rank r generated rows [r n_local, (r + 1) n_local) of this matrix
+    agg = eng.psis_loo(t, 190, "psis", 1.0, 0.7, pointwise=False)["agg"].cpu().numpy()
+    np.testing.assert_allclose(out["config"]["elpd_loo"], agg[1], rtol=1e-12)
+    assert out["config"]["n_high_k"] == agg[4]
+
+
+def test_bench_launches_four_ranks(eng):
+    """The flow the driver runs at 2, 4 and 8 GPUs, rehearsed at four ranks on one card over gloo (this pool allows six
+    processes on a card, the test runner being one of them: the 8-rank case is the driver's to start): rank count, per-rank
+    records, the label (a reduced rehearsal is not C4: tests/test_sharded_gloo.py checks the C4 switch through
+    bench.resolve_workload), the merged aggregates against one pass over the whole matrix."""
+    import torch
+
+    n_local, S = 4000, 4000
+    out = _run_bench(["--gpus", "4", "--obs", str(n_local), "--steps", "2", "--warmup", "1", "--no-cpu"],
+                     {"PYLOO_AMD_BENCH_BACKEND": "gloo", "PYLOO_AMD_BENCH_DEVICE": "0"})
+    assert out["n_gpus"] == 4 and out["ranks"] == 4 and out["backend"] == "gloo" and out["scaling"] == "weak"
+    assert out["devices_seen"] == [0, 0, 0, 0] and out["kernel_ms_per_rank"]["min"] <= out["kernel_ms_per_rank"]["max"]
+    assert out["config"]["workload"].startswith("custom:") and out["config"]["seed"] == "0x5eed0003"
+    assert {"PYLOO_AMD_BENCH_BACKEND=gloo", "PYLOO_AMD_BENCH_DEVICE=0"} <= set(out["env_overrides"]) and out["library_env_overrides"] == ""
+    assert out["stream_gave_up"] == 0
+    assert abs(out["value"] - 4 * n_local * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    t = torch.empty((4 * n_local, S), dtype=torch.float64, device="cuda")
     eng.fill_synthetic(t, seed=0x5EED0003)  # rank r generated rows [r n_local, (r + 1) n_local) of this matrix
     agg = eng.psis_loo(t, 190, "psis", 1.0, 0.7, pointwise=False)["agg"].cpu().numpy()
     np.testing.assert_allclose(out["config"]["elpd_loo"], agg[1], rtol=1e-12)

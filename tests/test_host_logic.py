@@ -288,3 +288,11 @@ def test_loo_subsample_posterior_correction(monkeypatch, oracle_engine):
     with pytest.warns(UserWarning, match="Importance resampling failed: .* Falling back to original samples."):
         fell_back = pl.loo_subsample(idata(ll), observations=obs, loo_approximation="lpd", reff=1.0, log_p=bad, log_q=log_q, seed=5)
     np.testing.assert_allclose(fell_back["elpd_loo"], plain["elpd_loo"], rtol=1e-12)
+    # log_p / log_q of another length than the draws: the reference's reshape to the stacked shape raises
+    # (loo_subsample.py:348-356) and the same fallback takes over -- shorter and longer
+    for n_other in (1500, 2500):
+        lq = rng.normal(size=n_other)
+        lp = lq + 0.5 * rng.normal(size=n_other)
+        with pytest.warns(UserWarning, match="Importance resampling failed: cannot reshape array of size .* Falling back to original samples."):
+            other = pl.loo_subsample(idata(ll), observations=obs, loo_approximation="lpd", reff=1.0, log_p=lp, log_q=lq, seed=5)
+        np.testing.assert_allclose(other["elpd_loo"], plain["elpd_loo"], rtol=1e-12)

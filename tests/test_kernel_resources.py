@@ -54,7 +54,7 @@ SCRATCH_OK = {
 
 @pytest.fixture(scope="module")
 def isa_lines(tmp_path_factory):
-    """The generated code of the kernel file, compiled ONCE for the tests of this module (100 s per compile)."""
+    """The generated code of the kernel units (csrc/pla_k_*.hip, compiled in parallel), ONCE for the tests of this module."""
     import isa_stats
 
     return isa_stats.compile_isa(out=str(tmp_path_factory.mktemp("isa") / "kernels.s"))

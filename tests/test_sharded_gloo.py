@@ -131,8 +131,9 @@ def _worker(rank, world, port, ll, reff, out_q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_obs", [37, 64])
-def test_two_ranks_match_single_process(n_obs):
+@pytest.mark.parametrize("n_obs,world", [(37, 2), (64, 2), (41, 8)])
+def test_ranks_match_single_process(n_obs, world):
+    """World size 2, and the node's 8 (uneven blocks: 41 observations over 8 ranks): the merged aggregates on every rank."""
     import torch.multiprocessing as mp
 
     rng = np.random.default_rng(n_obs)
@@ -145,10 +146,10 @@ def test_two_ranks_match_single_process(n_obs):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ll, reff, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ll, reff, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in procs]
+    got = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -161,20 +162,50 @@ def test_two_ranks_match_single_process(n_obs):
     assert sizes == n_obs  # pointwise outputs stay sharded
 
 
-def test_default_node_run_is_labelled_c4(monkeypatch):
-    """`bench.py --gpus 8` with the default workload is BASELINE.json's C4: its label and its seed."""
-    import importlib.util
+def test_a_launch_that_hangs_ends_with_exit_code_124():
+    """The real launcher, no stand-in: `python bench.py --gpus 2` whose ranks cannot finish inside the launch timeout (they
+    are still importing torch when it expires) -- the parent kills the launcher's process group (fresh children only: it
+    never touched the GPU itself) and exits with 124 instead of holding the node."""
     import subprocess
+    import time
+
+    env = dict(os.environ, PYLOO_AMD_BENCH_LAUNCH_TIMEOUT="0.2", PYLOO_AMD_BENCH_BACKEND="gloo", PYLOO_AMD_BENCH_DEVICE="0")
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--obs", "1000", "--steps", "1", "--warmup", "0",
+                          "--no-cpu"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 124, (out.returncode, out.stderr[-400:])
+    assert "did not finish within" in out.stderr and time.time() - t0 < 60
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]  # no record line from a launch that was cut off
+
+
+def test_default_node_run_is_labelled_c4():
+    """`bench.py --gpus 8` with the default workload is BASELINE.json's C4: its label and its seed --
+    through the function main() resolves its workload with, for the commands the driver runs at 1, 2, 4 and 8 GPUs."""
+    import argparse
+    import importlib.util
 
     spec = importlib.util.spec_from_file_location("bench_under_test2", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    src = open(os.path.join(ROOT, "bench.py")).read()
-    assert 'args.config, args.seed = "C4", 0x5EED0004' in src
-    for key in ('"rccl_version"', '"devices_seen"', '"kernel_ms_per_rank"', '"host_cpu"', '"host_cores"'):
-        assert key in src, key
+
+    def resolve(gpus, **over):
+        a = argparse.Namespace(gpus=gpus, obs=1_000_000, draws=4000, dtype="f64", seed=0x5EED0003, config=None)
+        for k, v in over.items():
+            setattr(a, k, v)
+        label, heavy, k_hi = bench.resolve_workload(a)
+        return a, label, heavy, k_hi
+
+    a, label, heavy, k_hi = resolve(8)
+    assert (label, a.config, a.seed, a.obs, a.draws, a.dtype) == ("C4", "C4", 0x5EED0004, 1_000_000, 4000, "f64")
+    for g in (1, 2, 4):
+        a, label, _, _ = resolve(g)
+        assert (label, a.config, a.seed) == ("C3", None, 0x5EED0003), g
+    a, label, heavy, k_hi = resolve(8, config="C5")
+    assert (label, a.obs, a.draws, a.dtype, a.seed, heavy, k_hi) == ("C5", 125_000, 20000, "f32", 0x5EED0005, (1.0, 1.3), 0.5)
+    a, label, _, _ = resolve(8, obs=4000)   # a reduced rehearsal is not C4
+    assert (label, a.config, a.seed) == ("custom", None, 0x5EED0003)
     assert isinstance(bench.host_cpu_model(), str) and bench.host_cpu_model()
-    del subprocess
 
 
 def test_device_side_merge_kernel_contract():

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static instruction mix of one kernel in the gfx950 ISA of pla_kernels.hip (no GPU needed).
+"""Static instruction mix of one kernel in the gfx950 ISA of the kernel units pyloo_amd/csrc/pla_k_*.hip (no GPU needed).
 
 usage: python tools/isa_stats.py [kernel-name-substring] [extra hipcc flags...]
 Prints VALU / SALU / LDS / VMEM counts, SGPR-spill traffic (v_writelane / v_readlane), scratch
@@ -15,12 +15,47 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def compile_isa(extra=(), out="/tmp/pla_isa.s"):
-    """One device-only compile of pla_kernels.hip to gfx950 assembly; returns the lines."""
-    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-disable-machine-licm",
-           "--offload-device-only", "-S", "-o", out, os.path.join(ROOT, "pyloo_amd/csrc/pla_kernels.hip")] + list(extra)
-    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
-    return open(out).read().split("\n")
+KERNEL_UNITS = ["pla_k_general.hip", "pla_k_wave_f64.hip", "pla_k_wave_f32.hip", "pla_k_chunked_f64.hip", "pla_k_chunked_f32.hip",
+                "pla_k_fit.hip", "pla_k_waic.hip", "pla_k_col.hip", "pla_k_eloo.hip"]
+
+
+def compile_isa(extra=(), out="/tmp/pla_isa.s", units=None):
+    """Device-only compiles of the kernel units (pyloo_amd/csrc/pla_k_*.hip) to gfx950 assembly, in parallel; returns the
+    lines of all of them, one after the other (also written to `out`).  Same flags as pyloo_amd/build.py."""
+    import concurrent.futures
+
+    units = list(units or KERNEL_UNITS)
+
+    def one(u):
+        dst = out + "." + u[:-4] + ".s"
+        cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-disable-machine-licm",
+               "--offload-device-only", "-S", "-o", dst, os.path.join(ROOT, "pyloo_amd/csrc", u)] + list(extra)
+        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        return open(dst).read()
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 1)) as pool:
+        text = "\n".join(pool.map(one, units))
+    with open(out, "w") as f:
+        f.write(text)
+    return text.split("\n")
+
+
+def unit_of(pat):
+    """The unit that holds a kernel (saves compiling the others when one kernel is asked for)."""
+    f32 = "If" in pat
+    if pat.startswith("wave_loo_chunked"):
+        return ["pla_k_chunked_f32.hip" if f32 else "pla_k_chunked_f64.hip"]
+    if pat.startswith(("wave_loo_kernel", "is_wave")):
+        return ["pla_k_wave_f32.hip" if f32 else "pla_k_wave_f64.hip"]
+    if pat.startswith("fit_rows"):
+        return ["pla_k_fit.hip"]
+    if pat.startswith(("col_", "tile_")):
+        return ["pla_k_col.hip"]
+    if pat.startswith("e_loo"):
+        return ["pla_k_eloo.hip"]
+    if pat.startswith("waic"):
+        return ["pla_k_waic.hip"]
+    return None
 
 
 def kernel_stats(lines, pat):
@@ -59,7 +94,7 @@ def kernel_stats(lines, pat):
 
 def main():
     pat = sys.argv[1] if len(sys.argv) > 1 else "wave_loo_kernelIdLi2"
-    lines = compile_isa(sys.argv[2:])
+    lines = compile_isa(sys.argv[2:], units=unit_of(pat))
     name, total, phases, res = kernel_stats(lines, pat)
     print(name)
     print(" total", dict(total))

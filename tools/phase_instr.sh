@@ -2,9 +2,8 @@
 # VALU instructions per row of the wave kernel by phase: PMC on the ablation build 
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-LIB=$ROOT/pyloo_amd/lib/libpyloo_amd_ablate.so
-hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -disable-machine-licm -DPLA_WAVE_ABLATE=1 -fPIC -shared \
-    -o "$LIB" "$ROOT/pyloo_amd/csrc/pla_kernels.hip" "$ROOT/pyloo_amd/csrc/pla_capi.hip"
+LIB=$ROOT/pyloo_amd/lib/alt_ablate.so
+(cd "$ROOT" && python -m pyloo_amd.build --alt=ablate -DPLA_WAVE_ABLATE=1 -DPLA_EXPERIMENT)
 cd /tmp && export TMPDIR=/tmp
 for sk in ${SKIPS:-0 1 4 5 7 8}; do
   rm -rf /tmp/pi_$sk
