@@ -187,6 +187,9 @@ struct EngineCall {
   EngineCall(pla_engine* e_, hipStream_t s_) : lock(e_->mu), e(e_), s(s_), ordered(false) {
     g_frozen = e->frozen;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+#if defined(PLA_NO_ORDER_EVENT)
+    return;
+#endif
     if (hipSetDevice(e->device) != hipSuccess || !e->order_event) return;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
       (void)hipGetLastError();
@@ -300,6 +303,7 @@ int pla_engine_create(int device, pla_engine** out) {
   hipError_t he = hipMalloc((void**)&e->counters, pla::kCountersTotal * sizeof(unsigned long long));
   if (he == hipSuccess) he = hipMalloc((void**)&e->d_red, (size_t)pla::reduce_workspace_doubles() * sizeof(double));
   if (he == hipSuccess) he = hipMemset(e->counters, 0, pla::kCountersTotal * sizeof(unsigned long long));
+  if (he == hipSuccess) he = hipMemset(e->d_red, 0, (size_t)pla::reduce_workspace_doubles() * sizeof(double));  // (the ticket of reduce_fused)
   if (he == hipSuccess) he = hipEventCreateWithFlags(&e->order_event, hipEventDisableTiming);
   for (int i = 0; i < pla_engine::kTimingRing && he == hipSuccess; ++i) {
     he = hipEventCreate(&e->ev0[i]);
@@ -801,6 +805,16 @@ static int psis_loo_impl(pla_engine* eng, const void* ll, int dtype, int64_t n_s
       PLA_HIP(hipMemcpy(h, eng->counters, sizeof(h), hipMemcpyDeviceToHost));
       if (h[3]) fprintf(stderr, "[pla] core clock %.1f MHz (%llu core ticks / %llu ticks of 100 MHz)\n",
                         100.0 * (double)h[2] / (double)h[3], h[2], h[3]);
+    }
+#endif
+#if defined(PLA_PHASE_CLOCK)
+    {  // diagnostic build: cycles per row of the wave kernel's waves, by phase (tools/phase_clock.sh)
+      unsigned long long h[16];
+      PLA_HIP(hipStreamSynchronize(s));
+      PLA_HIP(hipMemcpy(h, eng->counters, sizeof(h), hipMemcpyDeviceToHost));
+      const double rows = h[12] ? (double)h[12] : 1.0;
+      fprintf(stderr, "[pla] cycles per row and wave: statistics (incl. wait for the row) %.0f, threshold %.0f, sweep %.0f, selection %.0f; rows %llu\n",
+              h[8] / rows, h[9] / rows, h[10] / rows, h[11] / rows, h[12]);
     }
 #endif
     if (agg) {

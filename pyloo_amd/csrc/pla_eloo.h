@@ -1004,4 +1004,365 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 1) void e_loo_quantile_kernel(EQu
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weighted quantiles, fast path (round 4): ONE WAVEFRONT per observation, ONE trip over the two rows, no workgroup barrier
+// anywhere in the row loop.
+//
+// The 512-thread kernel above spends its time in ~30 block-wide exchanges per row (11.1 ms per 200 k x 4000
+// x 3 levels, 0.14 of what the two matrices cost to read).  Here a wave owns the row:
+//   * the draws and the log-weights pass through the registers once, in batches of eight 16-byte vectors each; the weights are
+//     taken against a RUNNING maximum of the log-weights that is brought up to date once per batch (wave-uniform; when it moves,
+//     the histogram so far is rescaled: twice per row on average);
+//   * ONE histogram of the row serves every level: 1024 bins linear in x between two bounds taken from the row's first 512
+//     draws and widened (draws outside fall into the end bins, which are settled like any other), the weight AND the number of the
+//     draws per bin (ds_add_f64 / ds_add_u32), both turned into running sums by a 16-bins-per-lane scan; every draw's bin number
+//     stays in LDS, two bytes each, in the order the lane met them;
+//   * a level = two look-ups in those sums -- the bin tb in which the cumulative weight reaches prob * total, and the last
+//     non-empty bin below it (by COUNT: a draw of negligible weight still is the reference's x_sorted[wi - 1]) -- one trip over
+//     the lane's bin numbers that collects the members of those two bins (a scalar branch skips the slots without one: most),
+//     their draws and log-weights read again from the matrices, and the settling of that list across the lanes: smallest member
+//     whose cumulative weight reaches the target, the weight below it, the first (lowest draw index) of the draws equal to it,
+//     the largest member below it -- exactly what the reference reads off its sorted arrays (e_loo.py:541-554).
+// Rows it does not take go on the device list for the general kernel above: non-finite draws or log-weights, constant
+// draws, weights that are all close (np.quantile's branch, e_loo.py:536-537), more than 64 draws in the two bins of a level, and
+// the measure-zero cases in which rounding puts the crossing on the other side of a bin edge.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kQWBins = 1024;
+constexpr int kQWBatch = 8;                          // vectors of each matrix in flight per lane
+struct QuantWaveSmem {
+  double hw[kQWBins];                                // weight per bin -> running sums
+  unsigned short hc[kQWBins];                        // draws per bin -> running sums (a row has at most 4096 draws; filled by 32-bit atomics on bin pairs)
+  unsigned short bins[kWave * (kWaveSlots + 4)];     // bin of every draw: lane l's slots at l * 68 (136 bytes: 8-byte aligned rows,
+                                                     // four lanes to a bank when all write the same slot)
+  int ms[kWave];                                     // members of the two bins of a level: draw index
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void e_loo_quantile_wave_kernel(EQuantParams P) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int NQ = kWaveSlots / VEC;
+  constexpr int kW = 4;
+  constexpr int kRow = kWaveSlots + 4;  // bin numbers per lane in LDS (padded)
+  __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];
+  __shared__ __attribute__((aligned(16))) QuantWaveSmem smem[kW];
+  const int tid = threadIdx.x;
+  for (int j = tid; j < kTabN; j += kWave * kW) exp_table_entry(tab, j);
+  __syncthreads();
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const int lane = tid & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+  QuantWaveSmem& sm = smem[wv];
+  const int S = __builtin_amdgcn_readfirstlane(P.n_draws);
+  const int n_probs = __builtin_amdgcn_readfirstlane(P.n_probs);
+  const int nvec = S / VEC, qfull = nvec / kWave, qrem = nvec - qfull * kWave;
+  const int nval = qfull + (lane < qrem ? 1 : 0);  // vectors of the row in this lane: vector q is inside the row iff q < nval
+  const double INF = pinf();
+  const auto wexp = [&](double d) { return exp_tab(fmax(d, -700.0), tab); };
+  const auto unpack = [](const v4i& t, double (&o)[VEC]) {
+    if constexpr (VEC == 2) {
+      o[0] = __hiloint2double(t[1], t[0]);
+      o[1] = __hiloint2double(t[3], t[2]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (double)__int_as_float(t[e]);
+    }
+  };
+  constexpr int PER = kQWBins / kWave;  // 16 bins per lane in the scans
+  const int64_t w0 = (int64_t)blockIdx.x * kW + wv, nw = (int64_t)gridDim.x * kW;
+#pragma unroll 1
+  for (int64_t r = w0; r < P.n_obs; r += nw) {
+    // (the arguments are read from the kernel's argument block where they are used -- scalar loads from constant memory -- not
+    // held in scalar registers across the row loop: the loop has none to spare, and scalars spilled into vector lanes have come
+    // back wrong in this build's fit kernel; tests/test_kernel_resources.py holds this kernel to zero such spills)
+    typedef const __attribute__((address_space(4))) EQuantParams* ArgPtr;
+    ArgPtr qp = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(qp));
+    const auto decline = [&]() {
+      if (lane == 0) qp->slow_list[atomicAdd(qp->slow_count, 1ull)] = (unsigned)r;
+    };
+    const T* xr = reinterpret_cast<const T*>(qp->x) + r * qp->stride_obs;
+    const T* wr = reinterpret_cast<const T*>(qp->lw) + r * qp->stride_obs;
+    const int bytes = S * (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xr), 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wr), 0, bytes, 0x00020000);
+    v4i tx[kQWBatch], tw[kQWBatch];
+    const auto load_batch = [&](int q0) {
+#pragma unroll
+      for (int u = 0; u < kQWBatch; ++u) {
+        tx[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, lane * 16, (q0 + u) * (kWave * 16), 2);  // (read once: non-temporal)
+        tw[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, (q0 + u) * (kWave * 16), 2);
+      }
+    };
+    load_batch(0);
+    wave_sync();  // (the previous row is done with the scratch)
+#pragma unroll 1
+    for (int b = lane; b < kQWBins; b += kWave) {
+      sm.hw[b] = 0.0;
+      sm.hc[b] = 0;
+    }
+    // ---- bounds of the bins from the first batch (8 x 64 vectors: the row's first 512 VEC draws, all inside the row) ---------
+    double blo, bhi;
+    {
+      double lo = INF, hi = -INF;
+#pragma unroll
+      for (int u = 0; u < kQWBatch; ++u) {
+        double x[VEC];
+        unpack(tx[u], x);
+        const bool valid = u < nval;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          lo = valid ? fmin(lo, x[e]) : lo;
+          hi = valid ? fmax(hi, x[e]) : hi;
+        }
+      }
+      double nlo;
+      wave_all2<R_MAX>(hi, -lo, bhi, nlo);
+      blo = -nlo;
+      const double pad = 0.25 * (bhi - blo);  // (the rest of the row reaches a little further: those draws land in the end bins)
+      blo -= pad;
+      bhi += pad;
+    }
+    // bin of a draw: round((x - blo) * scale) through the 2^52 trick, one fma + one clamp; monotone in x, which is all the
+    // levels need of it (NaN and +-inf never get here: the row is declined)
+    const double scale = (bhi > blo && bhi - blo < 1e300) ? (double)(kQWBins - 1) / (bhi - blo) : 0.0;
+    const double c0 = kMagic - blo * scale;
+    const auto bin_of = [&](double x) {
+      const int b = __double2loint(fma(x, scale, c0));
+      return b < 0 ? 0 : (b > kQWBins - 1 ? kQWBins - 1 : b);
+    };
+    wave_sync();
+    // ---- the trip over the row -----------------------------------------------------------------------------------------------
+    double mlw = -INF;                       // running maximum of the log-weights (wave-uniform)
+    double sa = 0.0, wmx = 0.0, wmn = INF;   // per lane, relative to mlw: sum, largest and smallest weight
+    double xlo = INF, xhi = -INF;
+    bool bad = false;
+    unsigned one = 1u;
+    asm volatile("" : "+v"(one));
+#pragma unroll 1
+    for (int q0 = 0; q0 < NQ; q0 += kQWBatch) {
+      double a[kQWBatch][VEC], x[kQWBatch][VEC];
+      double bm = -INF;
+#pragma unroll
+      for (int u = 0; u < kQWBatch; ++u) {
+        unpack(tx[u], x[u]);
+        unpack(tw[u], a[u]);
+        const bool valid = q0 + u < nval;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          bad |= valid & ((a[u][e] != a[u][e]) | !(fabs(x[u][e]) < INF));
+          bm = valid ? fmax(bm, a[u][e]) : bm;
+        }
+      }
+      if (q0 + kQWBatch < NQ) load_batch(q0 + kQWBatch);  // (the next batch flies while this one is worked on)
+      bm = wave_all<R_MAX>(bm);
+      if (bm > mlw) {  // (wave-uniform) a larger log-weight: bring what has been added up so far to the new maximum
+        const double f = (mlw > -INF) ? wexp(mlw - bm) : 0.0;
+        sa *= f;
+        wmx *= f;
+        wmn *= f;  // (INF stays INF)
+#pragma unroll 1
+        for (int b = lane; b < kQWBins; b += kWave) sm.hw[b] *= f;
+        mlw = bm;
+        wave_sync();
+      }
+      unsigned packed[kQWBatch * VEC / 2];
+#pragma unroll
+      for (int u = 0; u < kQWBatch; ++u) {
+        const bool valid = q0 + u < nval;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const double w = valid ? wexp(a[u][e] - mlw) : 0.0;
+          const int b = bin_of(x[u][e]);
+          if (valid) {
+            atomicAdd(&sm.hw[b], w);
+            atomicAdd(reinterpret_cast<unsigned*>(sm.hc) + (b >> 1), one << ((b & 1) << 4));
+          }
+          sa += w;
+          wmx = fmax(wmx, w);
+          wmn = valid ? fmin(wmn, w) : wmn;
+          xlo = valid ? fmin(xlo, x[u][e]) : xlo;
+          xhi = valid ? fmax(xhi, x[u][e]) : xhi;
+          const unsigned bb = valid ? (unsigned)b : 0xFFFFu;  // (0xFFFF: no draw in this slot)
+          const int k = u * VEC + e;
+          packed[k / 2] = (k & 1) ? (packed[k / 2] | (bb << 16)) : bb;
+        }
+        asm volatile("" : "+v"(sa), "+v"(wmx), "+v"(wmn));  // (a vector at a time: registers)
+      }
+      {  // the batch's bin numbers: kQWBatch * VEC of them, two bytes each, behind the lane's earlier ones
+        unsigned* dst = reinterpret_cast<unsigned*>(&sm.bins[lane * kRow + q0 * VEC]);
+#pragma unroll
+        for (int k = 0; k < kQWBatch * VEC / 2; k += 2) *reinterpret_cast<uint2*>(dst + k) = make_uint2(packed[k], packed[k + 1]);
+      }
+    }
+    double xmax, nxmin;
+    wave_all2<R_MAX>(xhi, -xlo, xmax, nxmin);
+    const double xmin = -nxmin;
+    if (__ballot(bad) != 0ull || !(fabs(mlw) < INF) || !(xmax > xmin) || !(scale > 0.0)) {
+      decline();
+      continue;
+    }
+    const double SA = wave_all<R_SUM>(sa);
+    double WMX, nWMN;
+    wave_all2<R_MAX>(wmx, -wmn, WMX, nWMN);
+    {  // np.allclose(weights, weights[0]) (e_loo.py:536): np.quantile's branch is the general kernel's
+      const double w0u = wexp(uniform_d((double)wr[0]) - mlw);
+      const double dev = fmax(WMX - w0u, w0u - (-nWMN));
+      if (dev <= kCloseAtol * SA + kCloseRtol * w0u) {
+        decline();
+        continue;
+      }
+    }
+    wave_sync();
+    // ---- running sums, 16 bins per lane around a scan of the lane totals (the bins are read twice: no register array) -----
+    double wincl;    // cumulative weight up to and including this lane's bins
+    unsigned cincl;  // ... and count
+    {
+      double run = 0.0;
+      unsigned crun = 0u;
+#pragma unroll
+      for (int i = 0; i < PER; i += 2) {
+        const double2 h = *reinterpret_cast<const double2*>(&sm.hw[lane * PER + i]);
+        run += h.x + h.y;
+      }
+      unsigned cw[PER / 2];  // the lane's 16 counts, two to a word
+      {
+        const uint4 h0 = *reinterpret_cast<const uint4*>(&sm.hc[lane * PER]);
+        const uint4 h1 = *reinterpret_cast<const uint4*>(&sm.hc[lane * PER + 8]);
+        cw[0] = h0.x; cw[1] = h0.y; cw[2] = h0.z; cw[3] = h0.w;
+        cw[4] = h1.x; cw[5] = h1.y; cw[6] = h1.z; cw[7] = h1.w;
+#pragma unroll
+        for (int i = 0; i < PER / 2; ++i) crun += (cw[i] & 0xFFFFu) + (cw[i] >> 16);
+      }
+      double incl = run;
+      unsigned ci = crun;
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const double up = __shfl_up(incl, o, kWave);
+        const unsigned cu = (unsigned)__shfl_up((int)ci, o, kWave);
+        if (lane >= o) {
+          incl += up;
+          ci += cu;
+        }
+      }
+      double acc = incl - run;
+      unsigned cacc = ci - crun;
+#pragma unroll
+      for (int i = 0; i < PER; i += 2) {
+        const double2 h = *reinterpret_cast<const double2*>(&sm.hw[lane * PER + i]);
+        const double c1 = acc + h.x, c2 = c1 + h.y;
+        *reinterpret_cast<double2*>(&sm.hw[lane * PER + i]) = make_double2(c1, c2);
+        acc = c2;
+      }
+#pragma unroll
+      for (int i = 0; i < PER / 2; ++i) {
+        const unsigned c1 = cacc + (cw[i] & 0xFFFFu), c2 = c1 + (cw[i] >> 16);
+        cw[i] = c1 | (c2 << 16);
+        cacc = c2;
+      }
+      *reinterpret_cast<uint4*>(&sm.hc[lane * PER]) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+      *reinterpret_cast<uint4*>(&sm.hc[lane * PER + 8]) = make_uint4(cw[4], cw[5], cw[6], cw[7]);
+      // (the lane's last running sum is what the look-ups compare with: the same additions in the same order)
+      wincl = acc;
+      cincl = cacc;
+    }
+    wave_sync();
+    const double WTOT = lane_value(wincl, kWave - 1);  // e_loo.py:542: cumsum / sum
+    bool give_up = false;
+    int np = n_probs;  // (opaque per row: the loop's entry test is made here, not kept as a scalar mask from the top of the kernel)
+    asm volatile("" : "+s"(np));
+#pragma unroll 1
+    for (int ip = 0; ip < np; ++ip) {
+      const double prob = uniform_d(qp->probs[ip]);
+      const double target = prob * WTOT;
+      double res;
+      // the bin in which the cumulative weight first reaches the target
+      const unsigned long long lhit = __ballot(wincl >= target);
+      if (lhit == 0ull) {
+        res = xmax;  // (545-546: the total never reaches the target)
+      } else {
+        const int L = __ffsll((long long)lhit) - 1;
+        const double cw = sm.hw[L * PER + (lane & (PER - 1))];
+        const unsigned long long bhit = __ballot(cw >= target) & 0xFFFFull;
+        const int tb = L * PER + (__ffsll((long long)bhit) - 1);
+        const unsigned cbelow = tb > 0 ? (unsigned)sm.hc[tb - 1] : 0u;  // draws in the bins below
+        int tlo = -1;                                          // the last non-empty bin below tb
+        if (cbelow > 0u) {
+          const unsigned long long l2 = __ballot(cincl >= cbelow);
+          const int L2 = __ffsll((long long)l2) - 1;
+          const unsigned cc = (unsigned)sm.hc[L2 * PER + (lane & (PER - 1))];
+          const unsigned long long b2 = __ballot(cc >= cbelow) & 0xFFFFull;
+          tlo = L2 * PER + (__ffsll((long long)b2) - 1);
+        }
+        const double base = tlo > 0 ? sm.hw[tlo - 1] : (tlo == 0 ? 0.0 : (tb > 0 ? sm.hw[tb - 1] : 0.0));
+        // ---- members of the two bins: one trip over the lane's bin numbers ----------------------------------------------
+        int nm = 0;
+        const unsigned utb = (unsigned)tb, utlo = tlo >= 0 ? (unsigned)tlo : 0xFFFEu;
+#pragma unroll 1
+        for (int k0 = 0; k0 < kWaveSlots; k0 += 8) {
+          const uint4 pk = *reinterpret_cast<const uint4*>(&sm.bins[lane * kRow + k0]);
+          const unsigned wd[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const unsigned b = (j & 1) ? (wd[j / 2] >> 16) : (wd[j / 2] & 0xFFFFu);
+            const bool hit = (b == utb) | (b == utlo);
+            const unsigned long long hm = __ballot(hit);
+            if (hm != 0ull) {  // (wave-uniform: most slots have no member)
+              const int pos = nm + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
+              if (hit && pos < kWave) {
+                const int k = k0 + j;  // slot of the lane: vector k / VEC, element k % VEC
+                sm.ms[pos] = VEC * (lane + kWave * (k / VEC)) + k % VEC;
+              }
+              nm += __popcll(hm);
+            }
+          }
+        }
+        wave_sync();
+        if (nm > kWave) {
+          give_up = true;
+          break;
+        }
+        const bool mine = lane < nm;
+        const int si = mine ? sm.ms[lane] : 0x7fffffff;
+        const double xm = mine ? (double)xr[si] : INF;
+        const double wm = mine ? wexp((double)wr[si] - mlw) : 0.0;
+        double upto = base, under = base;
+#pragma unroll 1
+        for (int j = 0; j < nm; ++j) {
+          const double xj = lane_value(xm, j), wj = lane_value(wm, j);
+          upto += (xj <= xm) ? wj : 0.0;
+          under += (xj < xm) ? wj : 0.0;
+        }
+        const bool reaches = mine && upto >= target;
+        const unsigned long long rm = __ballot(reaches);
+        if (rm == 0ull) {  // (rounding at the bin's edge: the general kernel decides)
+          give_up = true;
+          break;
+        }
+        const double v = wave_all<R_MIN>(reaches ? xm : INF);
+        if (bin_of(v) != tb) {  // (the crossing came out in the lower bin: its predecessor was not collected)
+          give_up = true;
+          break;
+        }
+        const unsigned long long vm = __ballot(mine && xm == v);
+        const double below = lane_value(under, __ffsll((long long)vm) - 1);
+        // the first (lowest draw index) of the draws equal to v, its weight, and the largest draw below v
+        const double sfirst = wave_all<R_MIN>((mine && xm == v) ? (double)si : 1e300);
+        const unsigned long long fm = __ballot(mine && (double)si == sfirst);
+        const double wfirst = lane_value(wm, __ffsll((long long)fm) - 1);
+        const double prev = wave_all<R_MAX>((mine && xm < v) ? xm : -INF);
+        // (e_loo.py:548-554; equal draws as the reference walks them: see the kernel above)
+        if (prev == -INF) res = v;
+        else if (!(below + wfirst >= target)) res = v;
+        else {
+          const double w1 = below / WTOT, wwi = (below + wfirst) / WTOT;
+          res = prev + (v - prev) * (prob - w1) / (wwi - w1);
+        }
+        wave_sync();  // (the member list is rewritten by the next level)
+      }
+      if (lane == 0) qp->out[r * n_probs + ip] = res;
+    }
+    if (give_up) decline();
+  }
+}
+
 }  // namespace pla

@@ -68,5 +68,15 @@ struct FastParams {
 #define PLA_QUEUE_CHUNK 16
 #endif
 constexpr int kQueueChunk = PLA_QUEUE_CHUNK;
+// Rows a wave of the wave kernel takes from the queue at a time: kQueueChunk, or a divisor of it -- the last units of a launch
+// are what the waves finish at different times, so the smaller the unit the shorter the stretch at the end of the kernel in
+// which the chip runs half empty (and the fit kernel beside it waits for the last flags).  done[c] COUNTS the rows of chunk c
+// that have been handed over (the fit kernel takes the chunk once all of them are there): a store of kQueueChunk when the unit
+// is the chunk, an agent-scope atomic add per unit otherwise.
+#ifndef PLA_QUEUE_UNIT
+#define PLA_QUEUE_UNIT 16
+#endif
+constexpr int kQueueUnit = PLA_QUEUE_UNIT;
+static_assert(kQueueChunk % kQueueUnit == 0, "a unit never straddles two chunks");
 
 }  // namespace pla

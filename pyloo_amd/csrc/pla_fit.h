@@ -42,6 +42,9 @@ constexpr int kFitCoefStride = 6;  // (VALU grid pass) doubles per quad in LDS, 
 #ifndef PLA_FIT_MIN_WAVES
 #define PLA_FIT_MIN_WAVES 2  // waves per SIMD the fit kernel is compiled for
 #endif
+#ifndef PLA_FIT_SORT_ROUNDS
+#define PLA_FIT_SORT_ROUNDS 3  // rounds (two passes each) of the odd-even transposition sort before the first look at whether the rows are sorted
+#endif
 #ifndef PLA_STREAM_SLEEP
 #define PLA_STREAM_SLEEP 32  // s_sleep argument between two looks at a chunk's flag (units of 64 cycles)
 #endif
@@ -156,6 +159,13 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
   } else {
     for (int j = tid; j < 64 * NQ; j += kWave * kFitWaves) l1s[j] = Q.l1_table[j < M ? j : M - 1];
   }
+  // (first and last grid point: read from LDS where they are used -- held in scalar registers across the group loop they are
+  // four of the registers the streamed kernel does not have)
+  __shared__ double g_ends[2];
+  if (tid == 0) {
+    g_ends[0] = Q.b_grid[0];
+    g_ends[1] = Q.b_grid[mestM - 1];
+  }
   __syncthreads();
   const double INF = pinf();
   const auto op_sum = [](double a, double b) { return a + b; };
@@ -193,7 +203,6 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     gact[c] = j < mestM;
     g[c] = Q.b_grid[gact[c] ? j : 0];
   }
-  const double g_first = Q.b_grid[0], g_last = Q.b_grid[mestM - 1];
   const int64_t ngroups = (Q.n_obs + 3) >> 2;
   const int t_lane = t;
   const int64_t nchunks = (Q.n_obs + kQueueChunk - 1) / kQueueChunk;
@@ -260,10 +269,10 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
         for (int i = 0; i < K - 1; ++i) u = u || (yb(i) < yb(i + 1));
         return __ballot(u) != 0ull;
       };
-      // bins of the selection histogram hold <= 8 values in all but a few per cent of the rows: four rounds (eight passes)
+      // bins of the selection histogram hold <= 6 values in all but a few per cent of the rows: three rounds (six passes)
       // finish those; the check keeps going for the rest (16 K passes sort ANY order, the cap is that bound)
 #pragma unroll 1
-      for (int it = 0; it < 4; ++it) sort_round();
+      for (int it = 0; it < PLA_FIT_SORT_ROUNDS; ++it) sort_round();
 #pragma unroll 1
       for (int it = 0; it < 8 * K && unsorted(); ++it) sort_round();
     PLA_PHASE(23);
@@ -287,6 +296,7 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     // b_j = g_j / (3 yq) + 1 / yn (psis.py:186-188), kept as the two per-observation scalars
     const double cb = recip_fast(3.0 * yq), db = recip_fast(yn);
     {
+      const double g_first = g_ends[0], g_last = g_ends[1];
       const double fbig = fma(-fma(g_first, cb, db), yn, 1.0), fsmall = fma(-fma(g_last, cb, db), yn, 1.0);
       if (!((fbig < 0x1p30) && (fsmall > 0x1p-30))) bad = true;
     }
@@ -517,14 +527,29 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     if (!(total > 1e-280) || !isfinite(loo) || !isfinite(lppd)) bad_out = true;
     const unsigned long long badm = __ballot(bad);
     const bool slow = (fit && ((badm >> (lane & 48)) & 0xFFFFull) != 0ull) || bad_out;
+    // (streamed kernel: what only the end of a group needs is read from the kernel's argument block HERE -- scalar loads from
+    // constant memory -- instead of living in scalar registers from the top of the kernel through every group: it has none to
+    // spare, and scalars it spilled into vector lanes have come back wrong -- see wait_for below)
+    typedef const __attribute__((address_space(4))) FitParams* ArgPtr;  // (constant address space: scalar loads)
+    double *pd = Q.diag, *pl = Q.loo_i, *pp = Q.lppd_i;
+    unsigned long long* pcount = Q.counters;
+    unsigned* plist = Q.slow_list;
+    unsigned sbase = Q.slow_base;
+    double scale = Q.scale_value;
+    if constexpr (STREAM) {
+      ArgPtr qp = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(qp));
+      pd = qp->diag; pl = qp->loo_i; pp = qp->lppd_i;
+      pcount = qp->counters; plist = qp->slow_list; sbase = qp->slow_base; scale = qp->scale_value;
+    }
     if (handled && t == 0) {
       if (slow) {
-        const unsigned long long idx = atomicAdd(&Q.counters[0], 1ull);
-        Q.slow_list[idx] = (unsigned)r + Q.slow_base;
+        const unsigned long long idx = atomicAdd(&pcount[0], 1ull);
+        plist[idx] = (unsigned)r + sbase;
       } else {
-        if (Q.diag) Q.diag[r] = fit ? khat : INF;
-        if (Q.loo_i) Q.loo_i[r] = Q.scale_value * loo;
-        if (Q.lppd_i) Q.lppd_i[r] = lppd;
+        if (pd) pd[r] = fit ? khat : INF;
+        if (pl) pl[r] = scale * loo;
+        if (pp) pp[r] = lppd;
       }
     }
   };
@@ -533,15 +558,38 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     // issued before this chunk's arithmetic, used behind it), looks at its flag (agent-scope loads, a sleep in between) and
     // posts it in LDS; the workgroup barrier stands between that poll and every load of the chunk's bytes.
     // false: gave up (see FitParams::patience)
-    const auto wait_for = [&](const int c) -> bool {
-      if (__hip_atomic_load(Q.done + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
-      unsigned long long mark = __builtin_amdgcn_s_memrealtime();
+    // (the state of the wait lives in VECTOR registers -- one lane runs this -- by force: left to itself the compiler keeps the
+    // clock, the queue position and the bounds in scalar registers, runs out of them and spills scalars into vector lanes
+    // from inside this one-lane branch, which the other waves of the workgroup then read back without ever having written
+    // them: groups of waves 1 and 3 went missing.  tests/test_kernel_resources.py holds this kernel to zero such spills.)
+    const auto wait_for = [&](int c) -> bool {
+      asm volatile("" : "+v"(c));
+#if defined(PLA_OLD_POLL)
+      unsigned looks = 0;
+      while (__hip_atomic_load(Q.done + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        if (++looks > 2000000u) {
+          __hip_atomic_store(Q.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return false;
+        }
+        __builtin_amdgcn_s_sleep(PLA_STREAM_SLEEP);
+      }
+      return true;
+#endif
+      // (done[c] counts the rows of chunk c that have been handed over: pla_fast.h, kQueueUnit)
+      const int64_t left = Q.n_obs - (int64_t)c * kQueueChunk;
+      unsigned need = left < kQueueChunk ? (unsigned)left : (unsigned)kQueueChunk;
+      asm volatile("" : "+v"(need));
+      if (__hip_atomic_load(Q.done + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+      // (32 bits of the 100 MHz counter: differences are good for 42 s)
+      unsigned mark = (unsigned)__builtin_amdgcn_s_memrealtime();
       unsigned seen = __hip_atomic_load(Q.producer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" : "+v"(mark), "+v"(seen));
       for (;;) {
         __builtin_amdgcn_s_sleep(PLA_STREAM_SLEEP);
-        if (__hip_atomic_load(Q.done + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
-        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-        if (now - mark > (unsigned long long)(seen ? Q.patience : Q.patience_start)) {
+        if (__hip_atomic_load(Q.done + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+        unsigned now = (unsigned)__builtin_amdgcn_s_memrealtime();
+        asm volatile("" : "+v"(now));
+        if (now - mark > (seen ? Q.patience : Q.patience_start)) {
           const unsigned q = __hip_atomic_load(Q.producer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (q == seen) {  // the producer's row queue stands still: it is not running beside this kernel
             __hip_atomic_store(Q.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -549,6 +597,7 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
           }
           seen = q;
           mark = now;
+          asm volatile("" : "+v"(mark), "+v"(seen));
         }
       }
     };

@@ -64,10 +64,10 @@ __global__ __launch_bounds__(BLOCK) void slow_rows_kernel(RowsParams P) {
 // and the chunk is L2-resident for the second pass.  Stage 2: one wave merges the chunk moments with
 // the pairwise update of Chan, Golub & LeVeque (no cancellation) in a fixed order.
 constexpr int kRedBlock = 256;
-constexpr int kRedChunks = 1024;
+constexpr int kRedChunks = 512;
 constexpr int kRedSlots = 8;  // n, sum loo, M2, sum lppd, #high, #non-finite, min diag, unused
 
-__global__ __launch_bounds__(kRedBlock) void reduce_stage1(ReduceParams P, double* part) {
+__device__ __forceinline__ void reduce_chunk(const ReduceParams& P, double* part) {
   __shared__ double red[16];
   const int tid = threadIdx.x;
   const int64_t per = (P.n_obs + gridDim.x - 1) / gridDim.x;
@@ -104,6 +104,8 @@ __global__ __launch_bounds__(kRedBlock) void reduce_stage1(ReduceParams P, doubl
   }
 }
 
+__global__ __launch_bounds__(kRedBlock) void reduce_stage1(ReduceParams P, double* part) { reduce_chunk(P, part); }
+
 struct Moments {  // count, mean and M2 of loo_i over a set of observations + the plain sums
   double n, mean, m2, s_loo, s_lppd, n_high, n_bad, dmin;
 };
@@ -121,8 +123,7 @@ __device__ __forceinline__ void merge_moments(Moments& a, const Moments& b) {  /
 // One wave: lane l merges chunks l*per .. (l+1)*per-1 in order, then the 64 partial results are merged
 // by a fixed shuffle tree.  The grouping depends only on the chunk count, so the result is
 // reproducible run to run.
-__global__ __launch_bounds__(kWave) void reduce_stage2(ReduceParams P, const double* part, int nchunks) {
-  const int lane = threadIdx.x;
+__device__ __forceinline__ void reduce_merge_wave(const ReduceParams& P, const double* part, int nchunks, int lane) {
   const int per = (nchunks + kWave - 1) / kWave;
   Moments a{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, pinf()};
   for (int c = lane * per; c < (lane + 1) * per && c < nchunks; ++c) {
@@ -147,6 +148,33 @@ __global__ __launch_bounds__(kWave) void reduce_stage2(ReduceParams P, const dou
   P.agg[PLA_AGG_N_NONFINITE] = n_bad;
   P.agg[PLA_AGG_MIN_DIAG] = dmin;
   P.agg[PLA_AGG_N_SLOW] = P.counters ? (double)P.counters[0] : 0.0;  // caller passes &counters[1]
+}
+// One wave: lane l merges chunks l*per .. (l+1)*per-1 in order, then the 64 partial results are merged
+// by a fixed shuffle tree.  The grouping depends only on the chunk count, so the result is
+// reproducible run to run.
+__global__ __launch_bounds__(kWave) void reduce_stage2(ReduceParams P, const double* part, int nchunks) {
+  reduce_merge_wave(P, part, nchunks, threadIdx.x);
+}
+// Both stages in ONE launch (a kernel boundary less behind every LOO pass): every workgroup writes its chunk's moments, makes
+// them visible at agent scope and takes a ticket; the workgroup whose ticket is the last one merges all chunks -- in chunk
+// order, whichever workgroup it is, so the bits do not depend on who came last -- and puts the ticket counter back to zero.
+// (`ticket`: one unsigned behind the partials, zero before the first launch and after every launch)
+__global__ __launch_bounds__(kRedBlock) void reduce_fused(ReduceParams P, double* part, unsigned* ticket) {
+  __shared__ unsigned s_last;
+  reduce_chunk(P, part);
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this chunk's moments before the ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the write-back has left before the ticket is taken: MI355X_MICROARCH.md, compiler hazard)
+    s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x < kWave) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every other chunk's moments behind their tickets
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    reduce_merge_wave(P, part, (int)gridDim.x, threadIdx.x);
+    if (threadIdx.x == 0) *ticket = 0u;
+  }
 }
 
 template <typename T>
@@ -447,17 +475,26 @@ hipError_t launch_clamp_rows(const int64_t* in, int64_t n_rows, int64_t n_src, i
   hipLaunchKernelGGL(clamp_rows_kernel, dim3((unsigned)g), dim3(256), 0, stream, in, n_rows, n_src, out);
   return hipGetLastError();
 }
-int reduce_workspace_doubles() { return kRedChunks * kRedSlots; }
+int reduce_workspace_doubles() { return kRedChunks * kRedSlots + 2; }  // (+ the ticket counter of reduce_fused: zeroed by the engine)
 
+#ifndef PLA_REDUCE_FUSED
+#define PLA_REDUCE_FUSED 1
+#endif
 hipError_t launch_reduce(const ReduceParams& p, double* workspace, hipStream_t stream) {
-  int64_t chunks = (p.n_obs + 1023) / 1024;  // >= 1024 observations per chunk
+  int64_t chunks = (p.n_obs + 1023) / 1024;  // >= 1024 observations per chunk, at most kRedChunks of them
   if (chunks < 1) chunks = 1;
   if (chunks > kRedChunks) chunks = kRedChunks;
+#if PLA_REDUCE_FUSED
+  hipLaunchKernelGGL(reduce_fused, dim3((unsigned)chunks), dim3(kRedBlock), 0, stream, p, workspace,
+                     reinterpret_cast<unsigned*>(workspace + kRedChunks * kRedSlots));
+  return hipGetLastError();
+#else
   hipLaunchKernelGGL(reduce_stage1, dim3((unsigned)chunks), dim3(kRedBlock), 0, stream, p, workspace);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(reduce_stage2, dim3(1), dim3(kWave), 0, stream, p, workspace, (int)chunks);
   return hipGetLastError();
+#endif
 }
 
 __global__ __launch_bounds__(kWave) void aggregate_pack_kernel(const double* agg, int rank, int world, double* table) {

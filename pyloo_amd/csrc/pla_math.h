@@ -98,8 +98,18 @@ __device__ __forceinline__ double recip_fast(double d) {
   r = fma(fma(-d, r, 1.0), r, r);
   return r;
 }
+// v_rcp_f64 is good to 2^-23; one Newton step squares that (2^-46) and the residual correction of the quotient squares it
+// again: q (1 - eps^2) with eps = 2^-46 -- the second Newton step of recip_fast would be wasted here
+#ifndef PLA_DIV_ONE_NEWTON
+#define PLA_DIV_ONE_NEWTON 1
+#endif
 __device__ __forceinline__ double div_fast(double a, double d) {
+#if PLA_DIV_ONE_NEWTON
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+#else
   const double r = recip_fast(d);
+#endif
   const double q = a * r;
   return fma(fma(-q, d, a), r, q);
 }

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
     __syncthreads();
     const unsigned again = (unsigned)__builtin_amdgcn_readfirstlane((int)sm.again);
     if constexpr (SYNC) {  // (a group that is swept again is the fit kernel's when that is over)
-      if (tid == 0 && again == 0u) __hip_atomic_store(&F.done[gp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0 && again == 0u) __hip_atomic_store(&F.done[gp], (unsigned)kQueueChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (all rows of the chunk: pla_fast.h, kQueueUnit)
     }
     return again;
   };

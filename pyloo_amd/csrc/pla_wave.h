@@ -251,6 +251,9 @@ struct WaveSmemT {
   double cand[CAP::kCand + 2 * kWave];  // candidate x values (+ 64 overflow slots + one dump slot per lane); reused for the
                                     // candidates sorted descending once they are binned
   double sa[CAP::kSa + 4];          // candidates at/above the boundary bin, grouped by bin (+ 4 sentinels); later y ascending
+#if defined(PLA_PHASE_CLOCK)
+  unsigned long long clk[8];        // diagnostic builds: cycles of this wave by phase (statistics incl. the wait for the row, threshold, sweep, selection) and rows
+#endif
 };
 // weights mode (psislw): the candidates carry their draw index so that the smoothed tail can be
 // written back to its positions
@@ -448,7 +451,6 @@ __device__ __forceinline__ int count_above(const T (&v)[kWaveSlots], T thr) {
   for (int i = 0; i < kWaveSlots; ++i) count_if<LW>(cnt, v[i], thr);
   return wave_sum_int(cnt);
 }
-
 // The speculative threshold comes from an order statistic of per-lane GROUP maxima over a sample of the row: a biased
 // quantile estimate when the draws of a group are dependent (autocorrelated MCMC output: the sample is made of 128-draw
 // blocks) and meaningless for rows that trend or are sorted.  So it is checked against what it is meant to deliver -- the
@@ -462,7 +464,10 @@ __device__ __forceinline__ bool wave_threshold_check(const T (&v)[kWaveSlots], c
                                                      const double raw_max, double& t_raw) {
   if (__builtin_amdgcn_readfirstlane(F.cr_hi) <= 0) return true;
   const auto stored = [](double raw) { return LW ? (T)raw : (T)(-raw); };
-  const int c0 = count_above<T, LW>(v, stored(t_raw));
+  // (counting every other vector only, with the band scaled to that half, was tried in round 4: -0.4 % on iid rows, but the
+  // half that is not counted differs enough on chain-major AR(1) rows to send 4 rows in 10 000 to the general kernel)
+  const auto count = [&](T thr) { return count_above<T, LW>(v, thr); };
+  const int c0 = count(stored(t_raw));
   if (c0 >= __builtin_amdgcn_readfirstlane(F.cr_lo) && c0 <= __builtin_amdgcn_readfirstlane(F.cr_hi)) return true;
   // (the bracket lives in vector registers: the callers' row loops are short of scalar ones)
   double lo = (c0 > __builtin_amdgcn_readfirstlane(F.cr_hi)) ? t_raw : raw_min;
@@ -472,7 +477,7 @@ __device__ __forceinline__ bool wave_threshold_check(const T (&v)[kWaveSlots], c
   for (int it = 0; it < 24; ++it) {
     double mid = 0.5 * (lo + hi);
     asm volatile("" : "+v"(mid));
-    const int c = count_above<T, LW>(v, stored(mid));
+    const int c = count(stored(mid));
     if (c > __builtin_amdgcn_readfirstlane(F.cr_hi)) lo = mid;
     else if (c < __builtin_amdgcn_readfirstlane(F.cr_lo)) hi = mid;
     else {
@@ -1163,6 +1168,17 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   const int qfull = nvec / kWave;                 // q < qfull: every lane valid
   const int qrem = nvec - qfull * kWave;          // q == qfull: lanes < qrem valid
 
+#if defined(PLA_PHASE_CLOCK)
+  unsigned long long clk_a = __builtin_amdgcn_s_memtime();
+#define PLA_CLK(k)                                                   \
+  do {                                                               \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+    if (lane == 0) sm.clk[k] += now_ - clk_a;                        \
+    clk_a = now_;                                                    \
+  } while (0)
+#else
+#define PLA_CLK(k) ((void)0)
+#endif
   // ---- finish the load issued by the previous iteration (or the prologue): pad fix-up -------------
   {
     // slots past the row: copy this lane's first vector (harmless for max / min / threshold)
@@ -1175,6 +1191,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   // spread over the row, see bitrev_order)
   double mx, mn, gs;
   row_stats<T, VEC, LW>(v, gsz, __builtin_amdgcn_readfirstlane(F.sample_bits), mx, mn, gs);
+  PLA_CLK(0);  // (statistics: includes the wait for the row's loads)
   double m, nmn, ngs, unused_;
   wave_all4<R_MAX>(mx, -mn, -gs, -gs, m, nmn, ngs, unused_);  // min = -max(-.): row max, row min, smallest group maximum
   mn = -nmn;
@@ -1211,6 +1228,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   // +-inf in the row makes R inf/NaN; a NaN draw is ignored by v_max here, poisons s1 in the sweep
   // and is caught by the finiteness test at the end: both land on the general kernel
   PLA_PHASE(1);
+  PLA_CLK(1);  // (reductions, threshold, exact count)
   bool slow = !(R < kWaveMaxRange) || !(t1 < 0.0) || !thr_ok;
   // constants every later phase uses, pinned in registers by hand (MachineLICM is off for this file:
   // the compiler would otherwise re-materialise them inside every loop)
@@ -1339,6 +1357,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     }
     const unsigned ncand = (next8 - cand0) >> 3;
     PLA_PHASE(3);
+    PLA_CLK(2);  // (sweep)
     {  // remove the pads' contribution (same code path, so it cancels to rounding)
       const double x = -R;
       const double t = fma(x, kC256, magic);
@@ -1377,6 +1396,10 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
   // the next row starts streaming into the (now dead) row registers while the outputs are stored and
   // the other wave of this SIMD computes
   PLA_PHASE(15);
+  PLA_CLK(3);  // (selection and hand-over)
+#if defined(PLA_PHASE_CLOCK)
+  if (lane == 0) sm.clk[4] += 1ull;
+#endif
   // (tail length -1: tells the fit kernel that this observation is on the list for the general kernel)
   if constexpr (SPLIT) {
     if (slow) ws_store_scalars<SYNC>(F, r, lane, 0.0, 0.0, 0.0, 0.0, 0.0, -1.0);
@@ -1429,6 +1452,9 @@ __global__ __launch_bounds__(kWave * CAP::kWaves, PLA_MIN_WAVES_PER_SIMD) void w
     for (int j = tid; j < P.tail_count; j += kWave * kWavesPerBlock) tb.l1[j] = F.l1_table[j];
     if (tid < kWave) tb.bg[tid] = F.b_grid[tid];
   }
+#if defined(PLA_PHASE_CLOCK)
+  if ((tid & (kWave - 1)) < 8) scratch[tid / kWave].clk[tid & 7] = 0ull;
+#endif
   __syncthreads();  // the only workgroup barrier: from here on the waves are independent
   const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);  // wave-uniform, and the compiler knows it
   SM& sm = scratch[wv];
@@ -1452,35 +1478,58 @@ __global__ __launch_bounds__(kWave * CAP::kWaves, PLA_MIN_WAVES_PER_SIMD) void w
   // (the queue's state in 32-bit scalars -- rows < 2^31 with a queue -- the row loop is short of scalar registers)
   const auto dequeue = [&]() -> unsigned {
     unsigned got = 0;
-    if (wave_lane() == 0) got = atomicAdd(F.queue, (unsigned)kQueueChunk);
+    if (wave_lane() == 0) got = atomicAdd(F.queue, (unsigned)kQueueUnit);
     return (unsigned)__builtin_amdgcn_readfirstlane((int)got);
   };
   const int64_t n = P.n_obs;
   int64_t r = w0;
   unsigned nxt = 0, chunk0 = 0;
-  int left = 0;  // rows of the current chunk after row r
+  int left = 0;  // rows of the current unit after row r
   if (queued) {
     chunk0 = dequeue();
     nxt = dequeue();
-    left = kQueueChunk - 1;
+    left = kQueueUnit - 1;
     r = (int64_t)chunk0;
   }
   if (r < n) issue_row_loads<T, VEC, LW ? 0 : PLA_LOAD_AUX>(v, base + PLA_ROW_OFFSET(P, r), P.n_draws);
+  // (the unit after the next is asked for BEFORE the last row of the current unit, not behind it: a returning atomic on a
+  // counter that 2048 waves share takes 1-3 us under this load, and waiting for it at the end of every unit was 0.8 % of the
+  // pass at 16 rows per unit -- with smaller units, which shorten the ragged end of the launch, it was everything: 4 rows per
+  // unit 8.1 ms against 6.4)
+#ifndef PLA_DEQUEUE_AHEAD
+#define PLA_DEQUEUE_AHEAD 1
+#endif
+  unsigned pend = 0;  // lane 0: the atomic's return value, in flight while the unit's last row is processed
 #pragma unroll 1
   while (r < n) {
     const int64_t rn = !queued ? r + nw : (left > 0 ? r + 1 : (int64_t)nxt);
+    if constexpr (PLA_DEQUEUE_AHEAD != 0 && kQueueUnit > 1) {
+      if (queued && (left == 0 || r + 1 >= n)) {
+        if (wave_lane() == 0) pend = atomicAdd(F.queue, (unsigned)kQueueUnit);
+      }
+    }
     wave_loo_row<T, VEC, LW, SM, TB, SPLIT, SYNC>(P, F, sm, tb, r, v, rn < n ? base + PLA_ROW_OFFSET(P, rn) : nullptr);
     if (queued) {
       if (left > 0 && r + 1 < n) {
         left -= 1;
       } else {
-        left = kQueueChunk - 1;
-        const unsigned after = dequeue();  // (its returned value is waited for: everything this wave has stored so far has drained)
+        left = kQueueUnit - 1;
+        unsigned after;
+        if constexpr (PLA_DEQUEUE_AHEAD != 0 && kQueueUnit > 1) after = (unsigned)__builtin_amdgcn_readfirstlane((int)pend);
+        else after = dequeue();  // (its returned value is waited for: everything this wave has stored so far has drained)
         if constexpr (SYNC) {
-          // streamed pass: chunk chunk0 / kQueueChunk is complete -- every hand-over store of its rows (sc1, whole lines) has
-          // left this wave -- and the fit kernel beside this one may take it
+          // streamed pass: the rows [chunk0, chunk0 + unit) are complete -- every hand-over store of theirs (sc1, whole lines) has
+          // left this wave -- and count towards their chunk; the fit kernel beside this one takes a chunk once all its rows count
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (said explicitly: the compiler may know the counter to be empty and drop its own)
-          if (wave_lane() == 0) __hip_atomic_store(F.done + chunk0 / kQueueChunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (wave_lane() == 0) {
+            if constexpr (kQueueUnit == kQueueChunk) {
+              __hip_atomic_store(F.done + chunk0 / kQueueChunk, (unsigned)kQueueChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+              const int64_t rest = n - (int64_t)chunk0;
+              (void)__hip_atomic_fetch_add(F.done + chunk0 / kQueueChunk, rest < kQueueUnit ? (unsigned)rest : (unsigned)kQueueUnit,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
         }
         chunk0 = nxt;
         nxt = after;
@@ -1488,6 +1537,9 @@ __global__ __launch_bounds__(kWave * CAP::kWaves, PLA_MIN_WAVES_PER_SIMD) void w
     }
     r = rn;
   }
+#if defined(PLA_PHASE_CLOCK)
+  if (wave_lane() < 5) atomicAdd(&F.counters[8 + wave_lane()], sm.clk[wave_lane()]);  // (profiling slots of the counters)
+#endif
 #if PLA_WAVE_ABLATE
   if (blockIdx.x == 0 && tid == 0) {  // core clock against the 100 MHz real-time counter
     unsigned long long ck1, rt1;

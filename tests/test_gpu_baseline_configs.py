@@ -117,8 +117,9 @@ def test_streamed_pass_equals_the_kernels_back_to_back(eng, n_obs, monkeypatch):
     for k in ref:
         same = (ref[k] == got[k]) | (torch.isnan(ref[k]) & torch.isnan(got[k]))
         assert bool(same.all()), ("gave up", k, int((~same).sum()))
+    gave_up = eng.stream_gave_up()
     if n_obs >= 1000:  # (with five rows the sweep may be over before the fit kernel looks at all)
-        assert eng.stream_gave_up() >= 1
+        assert gave_up >= 1
     assert eng.stream_gave_up() == 0  # (read and reset)
     # and against the oracle (a sample)
     idx = np.unique(np.linspace(0, n_obs - 1, 40).astype(np.int64))

@@ -80,6 +80,34 @@ def test_row_kernels_do_not_spill(isa_lines):
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+def test_quantile_wave_kernel_resources(isa_lines):
+    """The wave-per-observation quantile kernel (round 4): no scratch, no scalar registers spilled into vector lanes, two
+    workgroups of four waves per CU (LDS) at two waves per SIMD (registers)."""
+    import isa_stats
+
+    for pat in ("e_loo_quantile_wave_kernelId", "e_loo_quantile_wave_kernelIf"):
+        name, total, _, res = isa_stats.kernel_stats(isa_lines, pat)
+        assert res.get("ScratchSize", 0) == 0 and not any(k.startswith("scratch_") for k in total), (name, res)
+        assert total.get("v_writelane_b32", 0) == 0, (name, dict(total))
+        assert res["NumVgprs"] + res.get("NumAgprs", 0) <= 256 and 2 * res["LDSByteSize"] <= 160 * 1024, (name, res)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+def test_streamed_fit_kernel_spills_no_scalar_registers(isa_lines):
+    """Round 4: the streamed fit kernel of a build with ten scalar registers spilled into vector lanes (v_writelane at the top
+    of the kernel, v_readlane at the end of every group) skipped the output stores of whole groups of waves 1 and 3 -- the
+    null tests of the output pointers came back from the lanes as zero -- while the same source with six such spills did
+    not.  Every instantiation is held to none (what only the end of a group needs is read from the argument block there)."""
+    import isa_stats
+
+    for nq in (1, 2, 3, 4):
+        name, total, _, res = isa_stats.kernel_stats(isa_lines, f"fit_rows_stream_kernelILi{nq}")
+        assert total.get("v_writelane_b32", 0) == 0 and total.get("v_readlane_b32", 0) == 0, (name, dict(total))
+        assert res["NumVgprs"] + res.get("NumAgprs", 0) <= 128, (name, res)
+        assert res.get("ScratchSize", 0) <= (16 if nq == 4 else 0), (name, res)  # (four 64-value blocks: two registers in scratch)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
 def test_streamed_pass_kernels_fit_on_one_cu_together(isa_lines):
     """The streamed split pass needs two workgroups of the wave kernel AND one four-wave workgroup of the fit kernel resident on
     every CU at once: 512 vector registers per SIMD (allocated in eights) and 160 KB of LDS are the budget."""
