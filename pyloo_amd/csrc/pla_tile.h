@@ -116,7 +116,8 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
   constexpr int kStep = kSub * kTileWaves;          // draws per step of the workgroup: 32
   constexpr int kPer = kTileSample / kStep;         // sampled draws per lane: 16
   constexpr int kSelPer = kObs / kTileSelWaves;     // observations a selecting wave takes: 2
-  const int tid = (int)threadIdx.x;
+  int tid = (int)threadIdx.x;
+  const unsigned nblocks = gridDim.x;  // (read once: one scalar instead of a pointer into the hidden arguments kept for the loop)
   for (int j = tid; j < kTabN; j += kTileThreads) exp_table_entry(sm.tab, j);
   if constexpr (SYNC) {
     if (F.prio == 1) __builtin_amdgcn_s_setprio(1);
@@ -124,13 +125,16 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
     else if (F.prio == 3) __builtin_amdgcn_s_setprio(3);
   }
   __syncthreads();
-  const int w = __builtin_amdgcn_readfirstlane(tid / kWave);
-  const int lane = wave_lane();
-  const int o = lane & (kObs - 1), dsub = lane / kObs;
+  // (thread, wave and lane numbers are made opaque at the top of every trip of the group loop: the masks and LDS addresses
+  // derived from them are then computed where they are used instead of being kept in scalar registers from the top of the
+  // kernel -- the rest of the 65 scalars the kernel used to spill into vector lanes)
+  int w = __builtin_amdgcn_readfirstlane(tid / kWave);
+  int lane = wave_lane();
+  int o = lane & (kObs - 1), dsub = lane / kObs;
   const int S = P.n_draws, M = tail_count;
   const int64_t db = P.ld * (int64_t)sizeof(T);      // bytes between consecutive draws
-  const int64_t step_bytes = db * kStep;
-  const int nit = S / kStep;                         // whole steps
+  int64_t step_bytes = db * kStep;
+  int nit = S / kStep;                               // whole steps (both laundered per trip of the group loop, see below)
   const int64_t ngroups = (P.n_obs + kObs - 1) / kObs;
   const double INF = pinf();
   const char* tabc = reinterpret_cast<const char*>(sm.tab);
@@ -141,7 +145,22 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
   // draw) but comes round again: its threshold is corrected from the exact count the sweep has just made -- an exponential
   // tail through (threshold, count) and (row maximum, 1), as the long-row kernel's second attempts do (pla_chunked.h) -- and the
   // group is swept once more for it alone.  Returns the observations that want that (0 when first_try is false).
+  // (what the selection, the hand-over and the queue need of the launch's arguments is read from the argument block where it is
+  // used -- scalar loads from constant memory behind an opaque pointer -- instead of living in scalar registers through the
+  // sweep, which has none to spare: the kernel used to keep 65 scalars in vector lanes (v_writelane / v_readlane), a form that
+  // came back wrong in round 4's fit kernel; tests/test_kernel_resources.py now holds it to none)
+  struct TileArgs {
+    TileParams P;
+    FastParams F;
+    int tail_count;
+  };
+  typedef const __attribute__((address_space(4))) TileArgs* ArgPtr;
   const auto select_group = [&](const int64_t gp, const unsigned only, const bool first_try) -> unsigned {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass only parses this body; it has no constant address space to copy from)
+    ArgPtr qp = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(qp));
+    const FastParams F = qp->F;  // (shadows the kernel's: loaded here)
+#endif
     const int64_t obs0 = gp * kObs;
     if (tid == 0) sm.again = 0u;
     // the sweep's per-wave partial results first, for all of this wave's observations: they lie in the selection's scratch,
@@ -241,8 +260,7 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
   // row: a cluster every 32 draws; every chain of a chain-major stack contributes).  Nothing is loaded for the sample alone
   // (a sample of its own, read again by the sweep, was 11 % of the kernel's loads and of its HBM traffic).
   static_assert(kPer <= PLA_TILE_RING, "the sample is the head of the ring");
-  const int start_w = (int)(((int64_t)w * nit) / kTileWaves);       // first step of this wave's sweep
-  const int ahead0 = (PLA_TILE_RING + start_w) % nit;                // the step of visit R
+  int start_w = 0, ahead0 = 0;  // first step of this wave's sweep / the step of visit R (set at the top of every trip)
   // One trip of the loop: the sample loads of group g are ISSUED, the selection of the group before it runs on the lists in LDS
   // while they fly, then the sample is turned into thresholds and the group is swept.  (One place of issue for the sample; the
   // loop is entered with no group behind and left with none ahead.)
@@ -251,6 +269,13 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
   bool prev_first = true;        // ... for the first time
   unsigned redo = 0u;            // non-zero: group g is swept a second time, for these observations
   for (;;) {
+    asm volatile("" : "+v"(tid), "+v"(lane));
+    asm volatile("" : "+s"(w), "+s"(nit), "+s"(step_bytes));
+    o = lane & (kObs - 1);
+    dsub = lane / kObs;
+    start_w = (int)(((unsigned)w * (unsigned)nit) / (unsigned)kTileWaves);
+    ahead0 = PLA_TILE_RING + start_w;
+    ahead0 = ahead0 >= nit ? ahead0 - nit : ahead0;  // (nit >= the ring: tile_supported asks for 512 draws)
     const bool have = g < ngroups;
     const int64_t obs0 = g * kObs;
     // (lanes past the last observation of the launch re-read the last one; nothing of theirs is selected)
@@ -412,7 +437,11 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
     // a displaced workgroup's groups go to its neighbours.
     // (Back to back, the same counter evens out what the second sweeps and the last round of groups leave uneven: 9.1-9.4 ->
     // 8.8-8.9 ms on C3 when it came in.)
-    if (tid == 0 && redo == 0u) sm.next_group = gridDim.x + atomicAdd(F.queue, 1u);
+    if (tid == 0 && redo == 0u) {
+      ArgPtr qp = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(qp));
+      sm.next_group = nblocks + atomicAdd(qp->F.queue, 1u);
+    }
     // ---- C. the sweep ---------------------------------------------------------------------------------------------------------
     const double nmp = -sm.scal[o][0], nt_raw = -sm.scal[o][1];
     double nmn = INF, nmx = -INF, s1 = 0.0, s2 = 0.0;  // min / max of ll = -(max / min of raw)
@@ -521,7 +550,10 @@ __global__ __launch_bounds__(kTileThreads, 1) void tile_loo_kernel(TileParams P,
 #pragma unroll
       for (int u = 0; u < kPF; ++u) stage_b(u);
       // the steps behind the last whole round (already in the ring), and the draws behind the last whole step
-      const int left_steps = nit - nmain;
+      int left_steps = nit - nmain;
+      // (opaque per group: the fifteen tests below are then made here, scalar compare and branch, instead of being kept as
+      // fifteen 64-bit masks from the top of the kernel -- thirty of the scalars the kernel used to spill into vector lanes)
+      asm volatile("" : "+s"(left_steps));
       if (left_steps > 0) {
 #pragma unroll
         for (int u = 0; u < R - 1; ++u)
