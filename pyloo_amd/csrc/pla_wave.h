@@ -69,6 +69,9 @@ static_assert(PLA_FIT_SORTS == 1, "the hand-over is the tail's x grouped by bin 
 #ifndef PLA_LOAD_AUX
 #define PLA_LOAD_AUX 2  // cache policy of the single-read row loads: 2 = non-temporal
 #endif
+#ifndef PLA_LW_RESTREAM
+#define PLA_LW_RESTREAM 0  // weights mode: 1 = the sweep reads its own row a second time (rounds 1-3), 0 = the row stays in its registers
+#endif
 #ifndef PLA_BISECT_ITERS
 #define PLA_BISECT_ITERS 9
 #endif
@@ -530,7 +533,8 @@ __device__ __forceinline__ void lw_store_chunk(T (&v)[kWaveSlots], const __amdgp
     if constexpr (STREAM) issue_row_vector<T, VEC>(v, rs_next, q);
   }
 }
-// the smoothed tail at its positions (psis.py:155-158); must land after the row's stores
+// the smoothed tail at its positions (psis.py:155-158); must land after the row's stores (waiting for them to retire costs
+// nothing measurable: issuing the patch right behind them -- same wave, same addresses -- 7.27 against 7.27 ms)
 template <typename T, class SM, class TB>
 __device__ __forceinline__ void lw_patch_tail(SM& sm, const TB& tb, T* orow, const int lane, const int n, const double L) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1274,8 +1278,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     int four = 4;
     asm volatile("" : "+v"(four));
     // the next row (a zero-length range when there is none: the loads then return zeros and touch nothing)
-    // (weights mode streams the SAME row in again: its raw values are needed once more for the final
-    // pass, and holding them through selection and fit would spill)
+    // (weights mode, rounds 1-3, streamed the SAME row in again -- three row passes; PLA_LW_RESTREAM = 1 brings that back)
     const T* rp_stream = LW ? reinterpret_cast<const T*>(P.in) + PLA_ROW_OFFSET(P, r) : rp_next;
     const __amdgpu_buffer_rsrc_t rs_next = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>(rp_stream ? rp_stream : (const T*)P.in), 0, rp_stream ? S * (int)sizeof(T) : 0, 0x00020000);
@@ -1351,9 +1354,15 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
             sbase = q * (kWave * 16);
             asm volatile("" : "+s"(sbase));  // one scalar per four vectors (the compiler would materialise one per load)
           }
-          issue_row_vector<T, VEC, true>(v, rs_next, q, sbase);
+          if constexpr (!LW || PLA_LW_RESTREAM) issue_row_vector<T, VEC, true>(v, rs_next, q, sbase);
         }
       }
+    }
+    if constexpr (LW && !PLA_LW_RESTREAM) {
+      // weights mode keeps the row where it is: two row passes (one read, one write).  The registers are made opaque here so
+      // that the output pass recomputes x = raw - m from them instead of keeping the sweep's 64 shifted values alive
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) asm volatile("" : "+v"(v[i]));
     }
     const unsigned ncand = (next8 - cand0) >> 3;
     PLA_PHASE(3);
