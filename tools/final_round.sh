@@ -3,7 +3,7 @@
 # streamed pass, the bench lines and the side benches.  Everything lands under gpurun_out/final/ (copy what is to be kept
 # into profiles/).
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd "$ROOT"; mkdir -p gpurun_out/final; F=gpurun_out/final
 rm -f gpurun_out/handover_rates.jsonl
 PLA_HANDOVER_LOG=handover_rates.jsonl timeout -k 10 900 python -m pytest tests -m gpu -q > $F/gpu_tests.log 2>&1; r=$?
@@ -28,7 +28,9 @@ timeout -k 10 200 python tools/bench_e_loo.py 2>/dev/null > $F/${TAG}_bench_e_lo
 timeout -k 10 200 python tools/obs_fastest_cost.py 2>/dev/null > $F/${TAG}_bench_obs_fastest.json
 timeout -k 10 200 python tools/tile_time.py 2>/dev/null | tail -1 > $F/${TAG}_bench_obs_fastest_tile_streamed.json
 PLA_PIPE=0 timeout -k 10 200 python tools/tile_time.py 2>/dev/null | tail -1 > $F/${TAG}_bench_obs_fastest_tile_back_to_back.json
-PLA_NO_TILE=1 timeout -k 10 200 python tools/tile_time.py 2>/dev/null | tail -1 > $F/${TAG}_bench_obs_fastest_lane_per_observation.json
+# (PLA_NO_TILE is an experiment knob: compiled into an alternative build only)
+python -m pyloo_amd.build --alt=experiment -DPLA_EXPERIMENT > /dev/null 2>&1 && \
+  PYLOO_AMD_LIB=$ROOT/pyloo_amd/lib/alt_experiment.so PLA_NO_TILE=1 timeout -k 10 200 python tools/tile_time.py 2>/dev/null | tail -1 > $F/${TAG}_bench_obs_fastest_lane_per_observation.json
 timeout -k 10 200 python tools/waic_col_time.py 2>/dev/null | tail -1 > $F/${TAG}_bench_waic_obs_fastest.json
 bash tools/ktrace_tile_timeline.sh 2>&1 | grep -v "^W2026" > $F/${TAG}_tile_kernel_timeline.txt; echo "tile timeline done"
 OBS=262144 timeout -k 10 600 bash tools/pmc_col.sh > $F/${TAG}_col_traffic.txt 2>&1; echo "tile traffic done"
