@@ -137,8 +137,16 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
   __shared__ __attribute__((aligned(16))) double l1s[64 * NQ];
 #if PLA_FIT_MFMA
   constexpr int QN = 16 * NQ;  // quads per observation
+  // Long tails (NQ >= 5: the two-wave instantiations behind the chunked kernel) write and consume the quartic coefficients in
+  // TWO parts of KH 64-value blocks each: the scratch of a wave is then what the sort needs (4 x 64 NQ doubles) instead of the
+  // 5 x 4 x 16 NQ of all coefficients at once -- 14.3 instead of 17.9 KB at NQ = 7, four workgroups per CU instead of three
+  // (eight waves: what the registers allow anyway)
+  constexpr int kParts = (NQ >= 5 && !DYN) ? 2 : 1;
+  constexpr int KH = (NQ + kParts - 1) / kParts;  // 64-value blocks per part
+  constexpr int QH = 16 * KH;                      // quads per observation and part
+  constexpr int kWaveScratch = (5 * 4 * QH > 4 * 64 * NQ) ? 5 * 4 * QH : 4 * 64 * NQ;  // doubles (the sort's blocked copy lies here too)
   extern __shared__ __attribute__((aligned(16))) double coef_dyn[];
-  __shared__ __attribute__((aligned(16))) double coef_static[DYN ? 2 : kFitWaves * 5 * 4 * QN];  // per wave [coefficient k][observation][quad]
+  __shared__ __attribute__((aligned(16))) double coef_static[DYN ? 2 : kFitWaves * kWaveScratch];  // per wave [coefficient k][observation][quad]
   double* const coef = DYN ? coef_dyn : coef_static;
 #else
   __shared__ __attribute__((aligned(16))) double coef[kFitWaves * 4 * 16 * NQ * kFitCoefStride];
@@ -174,14 +182,14 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
   const int lane = wave_lane(), t = lane & 15, rho = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
 #if PLA_FIT_MFMA
-  double* ck = coef + (size_t)wv * (5 * 4 * QN);
+  double* ck = coef + (size_t)wv * kWaveScratch;
   double* ys_base = ck;  // (sorting scratch: 4 x 64 NQ doubles of this wave's coefficient area, which is written afterwards)
   // One MFMA evaluates 4 quads x 4 observations x 16 grid points: D[row][col] = C0 + sum_k A[row][k] B[k][col] with
   // tile row = observation + 4 * quad (so the four results a lane receives, rows rho + 4 i at column t, are four
   // quads of the lane's OWN observation at its own grid point), A[row][k] = C_(k+1) of that quad and
   // B[k][col] = g_col^(k+1).  Operand lane (t, rho) supplies A[row t][k rho] and B[k rho][col t].
-  const double* ckA = ck + ((rho + 1) * 4 + (t & 3)) * QN + (t >> 2);
-  const double* ckC = ck + rho * QN;
+  const double* ckA = ck + ((rho + 1) * 4 + (t & 3)) * QH + (t >> 2);
+  const double* ckC = ck + rho * QH;
   double gp[G];
 #pragma unroll
   for (int c = 0; c < G; ++c) {
@@ -304,30 +312,6 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     // ---- quartic coefficients of this lane's quads --------------------------------------------------------
     // 1 - b_j y = (1 - y/yn) - g_j y/(3 yq) = u + g_j t with u >= 0, t <= 0 and every g_j < 0: the product over
     // four y is a quartic in g_j whose terms are all non-negative (no cancellation)
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) {
-      const double y0 = yv[2 * k].x, y1 = yv[2 * k].y, y2 = yv[2 * k + 1].x, y3 = yv[2 * k + 1].y;
-      const double u0 = fma(-db, y0, 1.0), u1 = fma(-db, y1, 1.0), u2 = fma(-db, y2, 1.0), u3 = fma(-db, y3, 1.0);
-      const double t0 = -cb * y0, t1 = -cb * y1, t2 = -cb * y2, t3 = -cb * y3;
-      const double A0 = u0 * u1, A1 = fma(u0, t1, u1 * t0), A2 = t0 * t1;
-      const double B0 = u2 * u3, B1 = fma(u2, t3, u3 * t2), B2 = t2 * t3;
-#if PLA_FIT_MFMA
-      double* o = ck + rho * QN + (k * 16 + t);
-      o[0] = A0 * B0;
-      o[4 * QN] = fma(A0, B1, A1 * B0);
-      o[8 * QN] = fma(A0, B2, fma(A1, B1, A2 * B0));
-      o[12 * QN] = fma(A1, B2, A2 * B1);
-      o[16 * QN] = A2 * B2;
-#else
-      double* o = cf_row + (k * 16 + t) * kFitCoefStride;
-      *reinterpret_cast<double2*>(o) = make_double2(A0 * B0, fma(A0, B1, A1 * B0));
-      *reinterpret_cast<double2*>(o + 2) = make_double2(fma(A0, B2, fma(A1, B1, A2 * B0)), fma(A1, B2, A2 * B1));
-      o[4] = A2 * B2;
-#endif
-    }
-    wave_sync();
-    PLA_PHASE(26);
-    // ---- grid pass: three running products per lane over the 16 NQ quads of the observation -------------------
     double pm[G];
     int pe[G];
 #pragma unroll
@@ -336,27 +320,67 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
       pe[c] = 0;
     }
 #if PLA_FIT_MFMA
-#pragma unroll 1
-    for (int q4 = 0; q4 < QN; q4 += 8) {
 #pragma unroll
-      for (int u = 0; u < 8; u += 4) {
-        const double a = ckA[q4 + u];
-        const double2 c01 = *reinterpret_cast<const double2*>(ckC + q4 + u), c23 = *reinterpret_cast<const double2*>(ckC + q4 + u + 2);
-        const v4d cin = {c01.x, c01.y, c23.x, c23.y};
+    for (int part = 0; part < kParts; ++part) {
+      constexpr int kLastBlocks = NQ - (kParts - 1) * KH;  // blocks of the last part
+      const int k0 = part * KH, nk = (part == kParts - 1) ? kLastBlocks : KH;
+      if (part > 0) wave_sync();  // (the part before has been read)
 #pragma unroll
-        for (int c = 0; c < G; ++c) {
-          const v4d d = __builtin_amdgcn_mfma_f64_16x16x4f64(a, gp[c], cin, 0, 0, 0);
-          pm[c] *= (d[0] * d[1]) * (d[2] * d[3]);
+      for (int kk = 0; kk < KH; ++kk) {
+        if (kk < nk) {
+          const int k = k0 + kk;
+          const double y0 = yv[2 * k].x, y1 = yv[2 * k].y, y2 = yv[2 * k + 1].x, y3 = yv[2 * k + 1].y;
+          const double u0 = fma(-db, y0, 1.0), u1 = fma(-db, y1, 1.0), u2 = fma(-db, y2, 1.0), u3 = fma(-db, y3, 1.0);
+          const double t0 = -cb * y0, t1 = -cb * y1, t2 = -cb * y2, t3 = -cb * y3;
+          const double A0 = u0 * u1, A1 = fma(u0, t1, u1 * t0), A2 = t0 * t1;
+          const double B0 = u2 * u3, B1 = fma(u2, t3, u3 * t2), B2 = t2 * t3;
+          double* o = ck + rho * QH + (kk * 16 + t);
+          o[0] = A0 * B0;
+          o[4 * QH] = fma(A0, B1, A1 * B0);
+          o[8 * QH] = fma(A0, B2, fma(A1, B1, A2 * B0));
+          o[12 * QH] = fma(A1, B2, A2 * B1);
+          o[16 * QH] = A2 * B2;
         }
       }
-      // factors within 2^+-120 per quad: eight fit between renormalisations
+      wave_sync();
+      PLA_PHASE(26);
+      // ---- grid pass: three running products per lane over the 16 NQ quads of the observation -------------------
+#pragma unroll 1
+      for (int q4 = 0; q4 < 16 * nk; q4 += 8) {
 #pragma unroll
-      for (int c = 0; c < G; ++c) {
-        pe[c] += __builtin_amdgcn_frexp_exp(pm[c]);
-        pm[c] = __builtin_amdgcn_frexp_mant(pm[c]);
+        for (int u = 0; u < 8; u += 4) {
+          const double a = ckA[q4 + u];
+          const double2 c01 = *reinterpret_cast<const double2*>(ckC + q4 + u), c23 = *reinterpret_cast<const double2*>(ckC + q4 + u + 2);
+          const v4d cin = {c01.x, c01.y, c23.x, c23.y};
+#pragma unroll
+          for (int c = 0; c < G; ++c) {
+            const v4d d = __builtin_amdgcn_mfma_f64_16x16x4f64(a, gp[c], cin, 0, 0, 0);
+            pm[c] *= (d[0] * d[1]) * (d[2] * d[3]);
+          }
+        }
+        // factors within 2^+-120 per quad: eight fit between renormalisations
+#pragma unroll
+        for (int c = 0; c < G; ++c) {
+          pe[c] += __builtin_amdgcn_frexp_exp(pm[c]);
+          pm[c] = __builtin_amdgcn_frexp_mant(pm[c]);
+        }
       }
     }
 #else
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const double y0 = yv[2 * k].x, y1 = yv[2 * k].y, y2 = yv[2 * k + 1].x, y3 = yv[2 * k + 1].y;
+      const double u0 = fma(-db, y0, 1.0), u1 = fma(-db, y1, 1.0), u2 = fma(-db, y2, 1.0), u3 = fma(-db, y3, 1.0);
+      const double t0 = -cb * y0, t1 = -cb * y1, t2 = -cb * y2, t3 = -cb * y3;
+      const double A0 = u0 * u1, A1 = fma(u0, t1, u1 * t0), A2 = t0 * t1;
+      const double B0 = u2 * u3, B1 = fma(u2, t3, u3 * t2), B2 = t2 * t3;
+      double* o = cf_row + (k * 16 + t) * kFitCoefStride;
+      *reinterpret_cast<double2*>(o) = make_double2(A0 * B0, fma(A0, B1, A1 * B0));
+      *reinterpret_cast<double2*>(o + 2) = make_double2(fma(A0, B2, fma(A1, B1, A2 * B0)), fma(A1, B2, A2 * B1));
+      o[4] = A2 * B2;
+    }
+    wave_sync();
+    PLA_PHASE(26);
 #pragma unroll 1
     for (int q8 = 0; q8 < 16 * NQ; q8 += 8) {
 #pragma unroll

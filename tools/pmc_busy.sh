@@ -1,0 +1,20 @@
+#!/bin/bash
+# Issue counters per observation of every kernel of one bench pass (instructions, busy / wait cycles):
+#   BENCH_ARGS="--config C5" UNITS=125000 bash tools/pmc_busy.sh
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ARGS=${BENCH_ARGS:---obs 200000}
+UNITS=${UNITS:-200000}
+cd /tmp && export TMPDIR=/tmp
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS"; do
+rm -rf /tmp/pb; rocprofv3 --pmc $set --output-format csv -d /tmp/pb -- python3 $ROOT/bench.py $ARGS --steps 1 --warmup 1 --no-cpu > /tmp/pb.log 2>&1 || tail -3 /tmp/pb.log
+python3 - <<PY
+import csv, glob, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("/tmp/pb/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in acc.items():
+    if "pla::" in k and "fill" not in k and "zero" not in k:
+        print(k[:64], {c: round(sorted(v)[len(v)//2] / $UNITS, 1) for c, v in d.items()})
+PY
+done
