@@ -185,6 +185,19 @@ __device__ __forceinline__ float vmin_nc(float a, float b) {
   asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
+// three-operand forms (32-bit only on this target): two slots of an f32 row per instruction in the row's max / min pass
+template <bool NEG>
+__device__ __forceinline__ float vmax3_nc(float a, float b, float c) {
+  float d;
+  if constexpr (NEG) asm("v_max3_f32 %0, -%1, -%2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  else asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float vmin3_nc(float a, float b, float c) {
+  float d;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 template <RedOp OP>
 __device__ __forceinline__ double red2(double a, double b) {
   if constexpr (OP == R_SUM) return a + b;
@@ -385,15 +398,33 @@ __device__ __forceinline__ void row_stats_b(const T (&v)[kWaveSlots], const int 
   // chain is only two instructions long; four interleaved chains need none
   const T ninf = (T)(-pinf());
   T cur[2] = {ninf, ninf}, vmx[2] = {LW ? (T)pinf() : ninf, LW ? (T)pinf() : ninf}, snap = ninf;
+  if constexpr (sizeof(T) == 4) {
+    // f32 rows: v_max3_f32 / v_min3_f32 take two slots at a time -- one VALU operation per slot instead of two (the group
+    // boundaries 4, 8, 16, 32 fall between pairs; the slots of a pair lie in one 16-byte vector)
+    static_assert(VEC % 2 == 0, "pairs of slots inside a vector");
 #pragma unroll
-  for (int i = 0; i < kWaveSlots; ++i) {
-    const int sl = bitrev_order(i / VEC, B) * VEC + i % VEC;
-    cur[i & 1] = vmax_nc<!LW>(v[sl], cur[i & 1]);                                   // max raw
-    vmx[i & 1] = LW ? vmin_nc(v[sl], vmx[i & 1]) : vmax_nc<false>(v[sl], vmx[i & 1]);  // min raw (LOO: as max ll)
-    if (i == 3 || i == 7 || i == 15 || i == 31) {  // gsz is one of 4, 8, 16, 32 (wave_threshold_params)
-      if (gsz == i + 1) {
-        asm volatile("");  // a real wave-uniform branch, not a select per slot
-        snap = vmax_nc<false>(cur[0], cur[1]);
+    for (int i = 0; i < kWaveSlots; i += 2) {
+      const int s0 = bitrev_order(i / VEC, B) * VEC + i % VEC, s1 = s0 + 1, a = (i >> 1) & 1;
+      cur[a] = vmax3_nc<!LW>(v[s0], v[s1], cur[a]);
+      vmx[a] = LW ? vmin3_nc(v[s0], v[s1], vmx[a]) : vmax3_nc<false>(v[s0], v[s1], vmx[a]);
+      if (i == 2 || i == 6 || i == 14 || i == 30) {
+        if (gsz == i + 2) {
+          asm volatile("");
+          snap = vmax_nc<false>(cur[0], cur[1]);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < kWaveSlots; ++i) {
+      const int sl = bitrev_order(i / VEC, B) * VEC + i % VEC;
+      cur[i & 1] = vmax_nc<!LW>(v[sl], cur[i & 1]);                                   // max raw
+      vmx[i & 1] = LW ? vmin_nc(v[sl], vmx[i & 1]) : vmax_nc<false>(v[sl], vmx[i & 1]);  // min raw (LOO: as max ll)
+      if (i == 3 || i == 7 || i == 15 || i == 31) {  // gsz is one of 4, 8, 16, 32 (wave_threshold_params)
+        if (gsz == i + 1) {
+          asm volatile("");  // a real wave-uniform branch, not a select per slot
+          snap = vmax_nc<false>(cur[0], cur[1]);
+        }
       }
     }
   }
