@@ -489,8 +489,8 @@ struct EQuantParams {
   const double* probs;  // [n_probs] device
   int n_probs;
   double* out;          // [n_obs][n_probs]
-  // FAST variant: rows it does not take (non-finite or constant draws, more than 256 draws in a level's histogram bin) are
-  // listed here and redone by the general variant, which walks the list when one is given
+  // rows the wave-per-observation kernel does not take (non-finite or constant draws, too many draws in a level's histogram
+  // bins) are listed here and redone by the 512-thread kernel, which walks the list when one is given
   unsigned* slow_list = nullptr;
   unsigned long long* slow_count = nullptr;
 };
@@ -741,10 +741,11 @@ __device__ __forceinline__ int hist_select(Each each, const double target, const
   return 1;
 }
 
-// FAST: the histogram path only (no radix descent in the code: 60 registers less, two workgroups per CU instead of one, so
-// that one workgroup's barriers are another one's issue slots); GENERAL (FAST = false): everything, over the rows FAST listed.
-template <typename T, int BLOCK, bool FAST = false>
-__global__ __launch_bounds__(BLOCK, FAST ? 4 : 1) void e_loo_quantile_kernel(EQuantParams P) {
+// Over all rows, or -- behind the wave-per-observation kernel below -- over the rows that kernel listed (P.slow_list).
+// (Rounds 2-3 ran a second, histogram-only instantiation of this kernel in front of it, compiled for 128 registers with 132 bytes
+// of scratch; the wave kernel took its place in round 4.)
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK, 1) void e_loo_quantile_kernel(EQuantParams P) {
   __shared__ __attribute__((aligned(32))) double cum2k[kQBins];
   __shared__ __attribute__((aligned(32))) double scan[BLOCK];
   __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];  // table-driven exponential (pla_math.h): a third of libm's registers
@@ -759,10 +760,9 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 1) void e_loo_quantile_kernel(EQu
   __shared__ HistSelectScratch hsel[2];   // (hist_select's, in turns)
   const int tid = threadIdx.x;
   const int S = P.n_draws;
-  const int64_t n_rows = (!FAST && P.slow_list) ? (int64_t)*P.slow_count : P.n_obs;
+  const int64_t n_rows = P.slow_list ? (int64_t)*P.slow_count : P.n_obs;
   for (int64_t ri = blockIdx.x; ri < n_rows; ri += gridDim.x) {
-    const int64_t r = (!FAST && P.slow_list) ? (int64_t)P.slow_list[ri] : ri;
-    bool declined = false;  // (FAST: this row goes on the list)
+    const int64_t r = P.slow_list ? (int64_t)P.slow_list[ri] : ri;
     const T* xr = reinterpret_cast<const T*>(P.x) + r * P.stride_obs;
     const T* wr = reinterpret_cast<const T*>(P.lw) + r * P.stride_obs;
     const auto xat = [&](int s) { return (double)xr[(int64_t)s * P.stride_draw]; };
@@ -872,9 +872,6 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 1) void e_loo_quantile_kernel(EQu
     // one histogram of the row for every level (hist_select): rows kept in registers with finite, distinct extremes
     const bool hist_ok = kept && xmax > xmin && xmax - xmin < 1e300 && xmin > -1e300;
     const double qscale = hist_ok ? (double)kQBins / (xmax - xmin) : 0.0;
-    if constexpr (FAST) {
-      if (!hist_ok) declined = true;
-    }
     if (hist_ok) {
       for (int i = tid; i < kQBins; i += BLOCK) cum2k[i] = 0.0;
       __syncthreads();
@@ -916,7 +913,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 1) void e_loo_quantile_kernel(EQu
       __syncthreads();
     }
     int turn = 0;  // whose turn it is among hist_select's two scratches
-    for (int ip = 0; ip < P.n_probs && !declined; ++ip) {
+    for (int ip = 0; ip < P.n_probs; ++ip) {
       const double prob = P.probs[ip];
       double res;
       uint64_t kv = 0;
@@ -927,14 +924,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 1) void e_loo_quantile_kernel(EQu
         const double lo = floor(virt), t = virt - lo;
         int hs = hist_ok ? hist_select<BLOCK>(each_count, lo + 1.0, cum2k, xmin, qscale, &hsel[turn], &hsel[turn ^ 1], &kv, &below, &at) : -1;
         turn ^= hist_ok ? 1 : 0;
-        if constexpr (FAST) {
-          if (hs < 0) {
-            declined = true;
-            break;
-          }
-        } else {
-          if (hs < 0) mass_select<BLOCK>(each_count, lo + 1.0, hist, red, &qlist, &kv, &below, &at);
-        }
+        if (hs < 0) mass_select<BLOCK>(each_count, lo + 1.0, hist, red, &qlist, &kv, &below, &at);
         const double a = val_of(kv);
         double b = a;
         if (below + at < lo + 2.0 && lo + 1.0 < (double)S) {  // the next order statistic is the next distinct value
@@ -951,14 +941,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 1) void e_loo_quantile_kernel(EQu
         const int hs = hist_ok ? hist_select<BLOCK>(each, prob * wtot, cum2k, xmin, qscale, &hsel[turn], &hsel[turn ^ 1], &kv, &below, &at) : -1;
         turn ^= hist_ok ? 1 : 0;
         bool found = hs == 1;
-        if constexpr (FAST) {
-          if (hs < 0) {
-            declined = true;
-            break;
-          }
-        } else {
-          if (hs < 0) found = mass_select<BLOCK>(each, prob * wtot, hist, red, &qlist, &kv, &below, &at);
-        }
+        if (hs < 0) found = mass_select<BLOCK>(each, prob * wtot, hist, red, &qlist, &kv, &below, &at);
         if (!found) {
           res = xmax;                                                                     // 545-546
         } else {
@@ -997,9 +980,6 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 1) void e_loo_quantile_kernel(EQu
       }
       if (tid == 0) P.out[r * P.n_probs + ip] = res;
       __syncthreads();
-    }
-    if constexpr (FAST) {
-      if (declined && tid == 0) P.slow_list[atomicAdd(P.slow_count, 1ull)] = (unsigned)r;
     }
   }
 }

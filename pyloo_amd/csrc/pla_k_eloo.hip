@@ -51,32 +51,24 @@ hipError_t launch_e_loo_quantiles(const void* x, const void* lw, int dtype, int6
                                   unsigned long long* slow_count, hipStream_t stream) {
   if (n_obs <= 0 || n_probs <= 0) return hipSuccess;
   EQuantParams p{x, lw, n_obs, n_draws, stride_obs, stride_draw, probs, n_probs, out};
-  const int64_t grid = n_obs < 16384 ? n_obs : 16384;
   // Rows of up to 4096 contiguous, 16-byte aligned draws: ONE WAVE per observation, no workgroup barriers (e_loo_quantile_wave_kernel);
-  // other rows of up to 4096 draws: 512 threads per observation, eight draws per thread in registers (the FAST variant: histogram
-  // path only, 128 registers, two workgroups per CU).  The few rows either declines are listed for the general variant behind it.
-  const bool two = slow_list && slow_count && n_draws <= 4096 && n_obs <= 0xffffffffll;
+  // the few rows it declines are listed for the 512-thread kernel behind it, which takes every other shape whole.
   const int vec = dtype == PLA_F64 ? 2 : 4;
-  const bool wave = two && env_flag("PLA_FORCE_PATH") != 1 && stride_draw == 1 && (((uintptr_t)x | (uintptr_t)lw) % 16 == 0) && stride_obs % vec == 0 &&
-                    n_draws % vec == 0 && n_draws >= kWave * vec;
-  if (two) {
+  const bool wave = slow_list && slow_count && n_draws <= 4096 && n_obs <= 0xffffffffll && env_flag("PLA_FORCE_PATH") != 1 && stride_draw == 1 &&
+                    (((uintptr_t)x | (uintptr_t)lw) % 16 == 0) && stride_obs % vec == 0 && n_draws % vec == 0 && n_draws >= kWave * vec;
+  if (wave) {
     hipError_t e = hipMemsetAsync(slow_count, 0, sizeof(unsigned long long), stream);
     if (e != hipSuccess) return e;
     p.slow_list = slow_list;
     p.slow_count = slow_count;
-    if (wave) {
-      int64_t wg = (n_obs + 3) / 4;
-      if (wg > 4096) wg = 4096;
-      if (dtype == PLA_F64) hipLaunchKernelGGL(e_loo_quantile_wave_kernel<double>, dim3((unsigned)wg), dim3(256), 0, stream, p);
-      else hipLaunchKernelGGL(e_loo_quantile_wave_kernel<float>, dim3((unsigned)wg), dim3(256), 0, stream, p);
-    } else {
-      if (dtype == PLA_F64) hipLaunchKernelGGL((e_loo_quantile_kernel<double, 512, true>), dim3((unsigned)grid), dim3(512), 0, stream, p);
-      else hipLaunchKernelGGL((e_loo_quantile_kernel<float, 512, true>), dim3((unsigned)grid), dim3(512), 0, stream, p);
-    }
+    int64_t wg = (n_obs + 3) / 4;
+    if (wg > 4096) wg = 4096;
+    if (dtype == PLA_F64) hipLaunchKernelGGL(e_loo_quantile_wave_kernel<double>, dim3((unsigned)wg), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(e_loo_quantile_wave_kernel<float>, dim3((unsigned)wg), dim3(256), 0, stream, p);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
-  const int64_t g2 = two ? (n_obs < 2048 ? n_obs : 2048) : grid;
+  const int64_t g2 = wave ? (n_obs < 2048 ? n_obs : 2048) : (n_obs < 16384 ? n_obs : 16384);
   if (dtype == PLA_F64) hipLaunchKernelGGL((e_loo_quantile_kernel<double, 512>), dim3((unsigned)g2), dim3(512), 0, stream, p);
   else hipLaunchKernelGGL((e_loo_quantile_kernel<float, 512>), dim3((unsigned)g2), dim3(512), 0, stream, p);
   return hipGetLastError();

@@ -24,7 +24,7 @@ KERNELS = {
     "fit_rows_kernelILi4": 81920,
     "wave_loo_chunked_kernelIdLi2ENS_8CapsMid4ELb1": 81920,   # long rows / small reff, split pass (production)
     "wave_loo_chunked_kernelIfLi4ENS_7CapsMidELb1": 81920,    # C5: S = 20 000 f32, M = 425
-    "fit_rows_kernelILi7ELi4ELi2": 81920,                     # its fit half (448-value tails, 64-point grid)
+    "fit_rows_kernelILi7ELi4ELi2": 40960,                     # its fit half (448-value tails, 64-point grid): four workgroups per CU (round 4)
     "wave_loo_chunked_kernelIdLi2ENS_8CapsMid4ELb0ELb0": 81920,   # fused fallbacks (no workspace / M > 448)
     "wave_loo_chunked_kernelIfLi4ENS_7CapsMidELb0ELb0": 163840,   # (this fallback carries the fit's tables too: one workgroup per CU)
     "wave_loo_chunked_kernelIfLi4ENS_9CapsMidLWELb0ELb1": 163840,   # weights mode for long rows (psislw, S > 4096): one workgroup per CU
@@ -42,13 +42,7 @@ KERNELS = {
     "col_sweep_kernelIf": 81920,
     "col_select_kernel": 81920,
     "waic_col_kernelId": 81920,
-    "e_loo_quantile_kernelIdLi512ELb0": 81920,      # general variant (radix descent in its code)
-}
-# kernels that are allowed a few dwords of scratch, with the reason
-SCRATCH_OK = {
-    # FAST variant of the quantile kernel: compiled for 128 registers so that two 512-thread workgroups fit a CU (one
-    # workgroup's barriers are then the other's issue slots: 13.8 -> 11.9 ms); 34 dwords of invariants live in scratch
-    "e_loo_quantile_kernelIdLi512ELb1": 192,
+    "e_loo_quantile_kernelIdLi512": 81920,      # 512 threads per observation: the shapes / rows the wave kernel does not take
 }
 
 
@@ -73,10 +67,7 @@ def test_row_kernels_do_not_spill(isa_lines):
         assert total.get("v_writelane_b32", 0) <= allowed, (name, dict(total))
         assert not any(k.startswith("scratch_") for k in total), (name, dict(total))
         assert res.get("NumVgprs", 0) <= 256 and res.get("Occupancy", 0) >= 1, (name, res)
-        assert res.get("LDSByteSize", 0) <= lds_limit, (name, res)  # two workgroups per CU (160 KB LDS)
-    for pat, limit in SCRATCH_OK.items():
-        name, total, _, res = isa_stats.kernel_stats(lines, pat)
-        assert res.get("ScratchSize", 0) <= limit and res.get("NumVgprs", 0) <= 128, (name, res)
+        assert res.get("LDSByteSize", 0) <= lds_limit, (name, res)  # two (or the stated number of) workgroups per CU (160 KB LDS)
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")

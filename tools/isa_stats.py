@@ -2,6 +2,7 @@
 """Static instruction mix of one kernel in the gfx950 ISA of the kernel units pyloo_amd/csrc/pla_k_*.hip (no GPU needed).
 
 usage: python tools/isa_stats.py [kernel-name-substring] [extra hipcc flags...]
+       python tools/isa_stats.py --table      (every kernel with its registers / scratch / LDS, markdown)
 Prints VALU / SALU / LDS / VMEM counts, SGPR-spill traffic (v_writelane / v_readlane), scratch
 traffic, and the register budget the compiler reports.  If the source carries
 `asm volatile("; PLA_PHASE n")` markers the counts are also split by phase.
@@ -84,7 +85,7 @@ def kernel_stats(lines, pat):
                 c["branch"] += 1
     res = {}
     for l in lines[end:end + 600]:  # the resource comments follow the kernel descriptor
-        m = re.search(r"; (NumVgprs|NumAgprs|ScratchSize|Occupancy|LDSByteSize|NumSgprs): (\d+)", l)
+        m = re.search(r"; (NumVgprs|NumAgprs|ScratchSize|Occupancy|LDSByteSize|TotalNumSgprs): (\d+)", l)
         if m and m.group(1) not in res:
             res[m.group(1)] = int(m.group(2))
         if len(res) == 6:
@@ -92,7 +93,41 @@ def kernel_stats(lines, pat):
     return lines[start].split(":")[0], total, phases, res
 
 
+def demangle(names):
+    """c++filt over the mangled kernel names (the LLVM copy under /opt/rocm when binutils is absent)."""
+    for tool in ("c++filt", "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"):
+        try:
+            out = subprocess.run([tool], input="\n".join(names), capture_output=True, text=True, check=True).stdout.split("\n")
+            return dict(zip(names, out))
+        except (OSError, subprocess.CalledProcessError):
+            continue
+    return {n: n for n in names}
+
+
+def table(extra=()):
+    """Every kernel of the library with the resources its code object declares (markdown): `python tools/isa_stats.py --table`."""
+    lines = compile_isa(extra)
+    names = [m.group(1) for l in lines for m in [re.match(r"^(_Z\w+):\s*(;.*)?$", l)] if m and "pla" in m.group(1)]
+    kernels = []
+    for n in names:  # (kernels only: device functions have no .amdhsa_kernel descriptor)
+        if any(l.strip() == ".amdhsa_kernel " + n for l in lines):
+            kernels.append(n)
+    pretty = demangle(kernels)
+    rows = []
+    for n in kernels:
+        _, total, _, res = kernel_stats(lines, n[2:])
+        short = re.sub(r"\(.*", "", pretty[n]).replace("void ", "").replace("pla::", "")
+        rows.append((short, res.get("NumVgprs", 0), res.get("NumAgprs", 0), res.get("TotalNumSgprs", 0), res.get("ScratchSize", 0),
+                     res.get("LDSByteSize", 0), res.get("Occupancy", 0), total.get("v_writelane_b32", 0), total.get("VALU", 0)))
+    print("| kernel | VGPRs | AGPRs | SGPRs | scratch B | static LDS B | waves/SIMD (registers) | v_writelane | VALU instructions (static) |")
+    print("|---|---|---|---|---|---|---|---|---|")
+    for r in sorted(rows):
+        print("| `" + r[0] + "` | " + " | ".join(str(x) for x in r[1:]) + " |")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--table":
+        return table(sys.argv[2:])
     pat = sys.argv[1] if len(sys.argv) > 1 else "wave_loo_kernelIdLi2"
     lines = compile_isa(sys.argv[2:], units=unit_of(pat))
     name, total, phases, res = kernel_stats(lines, pat)
