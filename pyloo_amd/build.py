@@ -23,7 +23,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpyloo_amd.so")
 SOURCES = [
     "pla_k_general.hip", "pla_k_wave_f64.hip", "pla_k_wave_f32.hip", "pla_k_chunked_f64.hip", "pla_k_chunked_f32.hip",
-    "pla_k_fit.hip", "pla_k_waic.hip", "pla_k_col.hip", "pla_k_eloo.hip", "pla_capi.hip",
+    "pla_k_fit.hip", "pla_k_lwout.hip", "pla_k_waic.hip", "pla_k_col.hip", "pla_k_eloo.hip", "pla_capi.hip",
 ]
 PUBLIC_HEADER = os.path.join(HERE, "..", "include", "pyloo_amd.h")
 ARCH = "gfx950"

@@ -954,9 +954,38 @@ int pla_importance_weights(pla_engine* eng, const void* logw, int dtype, int64_t
     p.stride_draw = stride_draw;
     p.diag = diag;
     p.lw_out = lw_out;
+    // Rows longer than the registers (S > 4096) with tails the fit kernel takes: the split weights pass (selection kernel -> fit
+    // kernel -> output kernel, csrc/pla_lwout.h) needs the hand-over buffers -- tail x, smoothed weights by rank, scalars -- for
+    // the rows of one launch, so such calls run in blocks of 2^17 observations (0.94 GB at 448-value tails).  No room: the
+    // fused weights kernel, which needs none.
+    int64_t block = n_obs;
+    if (method == PLA_PSIS && n_draws > 4096 && tail_count <= 448 && stride_draw == 1 && n_obs > 0) {
+      const int64_t kLwBlock = (int64_t)1 << 17;
+      block = n_obs < kLwBlock ? n_obs : kLwBlock;
+      const int stride = (int)((tail_count + 63) & ~(int64_t)63);
+      rc = grow(&eng->d_ws, &eng->d_ws_bytes, (size_t)block * (size_t)(2 * stride + 8) * sizeof(double));
+      if (rc == PLA_ERR_NOMEM) {
+        block = n_obs;
+      } else {
+        if (rc) return rc;
+        p.ws_y = (double*)eng->d_ws;
+        p.ws_w = p.ws_y + (size_t)block * stride;
+        p.ws_s = p.ws_w + (size_t)block * stride;
+        p.ws_stride = stride;
+        p.ws_sstride = 8;
+      }
+    }
     TimedLaunch t(eng, s);
-    PLA_HIP(pla::launch_rows(p, dtype, true, s));
+    for (int64_t r0 = 0; r0 < n_obs || r0 == 0; r0 += block) {
+      const int64_t nr = (n_obs - r0 < block) ? (n_obs - r0) : block;
+      p.in = (const char*)logw + (size_t)r0 * (size_t)stride_obs * esz;
+      p.n_obs = nr;
+      p.diag = diag ? diag + r0 : nullptr;
+      p.lw_out = (char*)lw_out + (size_t)r0 * (size_t)n_draws * esz;
+      PLA_HIP(pla::launch_rows(p, dtype, true, s));
       eng->last_kernels = pla::last_rows_kernels();
+      if (n_obs == 0) break;
+    }
     return PLA_OK;
   }
 
@@ -970,6 +999,18 @@ int pla_importance_weights(pla_engine* eng, const void* logw, int dtype, int64_t
   if (rc) return rc;
   rc = grow(&eng->d_lw, &eng->d_lw_bytes, (size_t)rows_per_chunk * row_bytes);
   if (rc) return rc;
+  if (method == PLA_PSIS && n_draws > 4096 && tail_count <= 448) {  // (the split weights pass of long rows, as on the device path)
+    const int stride = (int)((tail_count + 63) & ~(int64_t)63);
+    rc = grow(&eng->d_ws, &eng->d_ws_bytes, (size_t)rows_per_chunk * (size_t)(2 * stride + 8) * sizeof(double));
+    if (rc && rc != PLA_ERR_NOMEM) return rc;
+    if (!rc) {
+      p.ws_y = (double*)eng->d_ws;
+      p.ws_w = p.ws_y + (size_t)rows_per_chunk * stride;
+      p.ws_s = p.ws_w + (size_t)rows_per_chunk * stride;
+      p.ws_stride = stride;
+      p.ws_sstride = 8;
+    }
+  }
   {
     size_t have_b = eng->d_pw_elems * sizeof(double);
     rc = grow((void**)&eng->d_pw, &have_b, (size_t)(3 * n_obs + PLA_AGG_COUNT) * sizeof(double));

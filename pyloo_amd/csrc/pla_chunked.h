@@ -44,6 +44,10 @@ template <typename T, int VEC, typename SM, typename TB, bool SPLIT = false, boo
 __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const FastParams& F, SM& sm, const TB& tb,
                                                     const int64_t r, T (&v)[kWaveSlots], const T* row, const T* rp_next,
                                                     const ChunkRetry& now, ChunkRetry& want) {
+  // LW with SPLIT (weights of long rows, round 4): only the SIGN convention of weights mode -- raw = the input, not its negative
+  // -- and everything else as in the LOO split pass: no draw indices, no output pass here (the fit kernel and lw_output_kernel
+  // follow, pla_lwout.h).  LWF: the fused weights mode of rounds 2-3.
+  constexpr bool LWF = LW && !SPLIT;
   const bool second = now.attempt > 0;
   const double t_second = now.t_raw, m_second = now.m_raw;
   constexpr int EPT = kWaveSlots;
@@ -148,7 +152,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
     asm volatile("" : "+v"(four));
     // what streams in behind the sweep: the next chunk of this row, or the first chunk of the next row
     // (weights mode: the row's own first chunk again, for the output pass)
-    const T* rp_stream = last ? (LW ? row : rp_next) : row + (int64_t)(ch + 1) * kChunkDraws;
+    const T* rp_stream = last ? (LWF ? row : rp_next) : row + (int64_t)(ch + 1) * kChunkDraws;
     int bytes_stream = 0;
     if (rp_stream) {
       const int left = last ? S : S - (ch + 1) * kChunkDraws;
@@ -189,7 +193,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
         unsigned pos8 = (rank << 3) + base8;
         asm("" : "+v"(pos8));
         lds_store(cand ? pos8 : dump8, (double)v[i]);  // the INPUT value: x = -value - m follows after the last chunk
-        if constexpr (LW)  // draw index of the candidate: 4096 ch + VEC * (lane + 64 q) + e for slot i = q VEC + e
+        if constexpr (LWF)  // draw index of the candidate: 4096 ch + VEC * (lane + 64 q) + e for slot i = q VEC + e
           sm.ids[cand ? ((pos8 - cand0) >> 3) : (unsigned)(kCand + kWave + lane)] =
               (unsigned short)(id_base + (VEC * kWave * (i / VEC) + i % VEC));
         {
@@ -224,7 +228,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
   if (nch == 1) c_first = ncand;
   if (!slow && ((int)ncand < M + 1 || ncand > (unsigned)kCand)) {
     slow = true;
-    if constexpr (!LW) {
+    if constexpr (!LWF) {
       if (now.attempt + 1 < kChunkAttempts && F.retry_target > 0 && c_first >= 8u && ncand >= 8u && R < kWaveMaxRange) {
         // The next threshold, from EXACT counts of this row (dependence between neighbouring draws does not bias them) and an
         // exponential tail, log count(t) = a - lambda t:
@@ -277,7 +281,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
                                                sh, magic, c256, nvl / kWave, nvl % kWave, slow, khat, loo, lppd);
     }
   }
-  if constexpr (LW) {
+  if constexpr (LWF) {
     // ---- weights mode: the row passes through the registers once more (its first chunk came in behind the last sweep),
     // each vector stored as lw = (raw - m) - L and replaced by the same vector of the following chunk; then the smoothed tail
     if (!slow) {
@@ -322,7 +326,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row_chunked(const RowsParams& P, const F
 
 template <typename T, int VEC, class CAP, bool SPLIT = false, bool LW = false>
 __global__ __launch_bounds__(kWave * CAP::kWaves, 1) void wave_loo_chunked_kernel(RowsParams P, FastParams F) {
-  using SM = std::conditional_t<LW, WaveSmemLWT<CAP>, WaveSmemT<CAP>>;
+  using SM = std::conditional_t<LW && !SPLIT, WaveSmemLWT<CAP>, WaveSmemT<CAP>>;
   using TB = std::conditional_t<SPLIT, WaveTabOnly, WaveTablesT<CAP>>;
   constexpr int kWavesPerBlock = CAP::kWaves;
   __shared__ __attribute__((aligned(16))) SM scratch[kWavesPerBlock];

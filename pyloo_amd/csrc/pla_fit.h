@@ -83,6 +83,11 @@ struct FitParams {
   const unsigned* producer = nullptr;
   unsigned patience = 0, patience_start = 0;
   unsigned long long* gave_up_total = nullptr;  // engine statistics: passes in which the streamed fit gave up (plain fit kernel, leftovers)
+  // WEIGHTS mode (psislw of rows longer than the registers: selection kernel -> this kernel -> lw_output_kernel, pla_lwout.h):
+  // non-null = this kernel writes, per observation, the tail's x back to ws_y SORTED (descending rank p at [p]), the smoothed
+  // weight of rank p to ws_w[p], and into the scalars log(sum of the smoothed weights) at [2] and the number of tail draws to
+  // patch at [5] (0: nothing was smoothed; -1: on the list for the general kernel); k-hat goes to `diag` as in LOO mode
+  double* ws_w = nullptr;
 };
 
 // 16 bytes of the hand-over.  STREAM: an agent-scope (sc1) load straight from memory -- the bytes were written, by the kernel
@@ -284,6 +289,13 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
 #pragma unroll 1
       for (int it = 0; it < 8 * K && unsorted(); ++it) sort_round();
     PLA_PHASE(23);
+      if constexpr (!STREAM) {
+        if (Q.ws_w && handled && fit) {  // weights mode: the output pass ranks the row's tail draws against this (pla_lwout.h)
+          double* ysorted = const_cast<double*>(Q.ws_y) + y0;
+#pragma unroll
+          for (int i = 0; i < 2 * NQ; ++i) *reinterpret_cast<double2*>(ysorted + K * t + 2 * i) = yv[i];
+        }
+      }
       // y = e^x - e^xcut (psis.py:147) of the sorted tail; ranks from n on are padding (x = xcut): y = 0 exactly
 #pragma unroll
       for (int i = 0; i < 2 * NQ; ++i) yv[i] = make_double2(exp_tab(yv[i].x, tab) - e_cut, exp_tab(yv[i].y, tab) - e_cut);
@@ -495,12 +507,13 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     if (smoothed && (!(sigma > 0.0) || fabs(khat) < kEps)) bad = true;
     const double coef_s = sigma / khat, off = e_cut - coef_s;
     double acc_t = 0.0, acc_r = 0.0;
-    const auto smooth = [&](int j, double l1, double yj) {
+    const auto smooth = [&](int j, double l1, double yj) -> double {
       const double ez = exp_tab(fmin(-khat * l1, 700.0), tab);
       const double wj = fmin(fma(ez, coef_s, off), 1.0);  // exp(log(q + e_cut)) clipped at 0 (psis.py:155,157)
       const double ej = yj + e_cut;
       acc_t += (j < n) ? wj - ej : 0.0;
       acc_r += (j < n) ? div_fast(wj, ej) : 0.0;
+      return wj;
     };
     // (the sums are pinned every few elements: left alone, the scheduler starts every element at once and spills)
     const auto pin = [&]() { asm volatile("" : "+v"(acc_t), "+v"(acc_r)); };
@@ -515,8 +528,11 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
           asm volatile("");
           if (n != M) l1 = make_double2(log_fast(1.0 - ((double)(n - 1 - p) + 0.5) * rn), log_fast(1.0 - ((double)(n - 2 - p) + 0.5) * rn));
         }
-        smooth(p, l1.x, yv[i].x);
-        smooth(p + 1, l1.y, yv[i].y);
+        const double w0 = smooth(p, l1.x, yv[i].x);
+        const double w1 = smooth(p + 1, l1.y, yv[i].y);
+        if constexpr (!STREAM) {
+          if (Q.ws_w && handled && smoothed) *reinterpret_cast<double2*>(Q.ws_w + y0 + p) = make_double2(w0, w1);  // (weights mode: rank p's smoothed weight)
+        }
         if ((i % PLA_FIT_PIN) == PLA_FIT_PIN - 1) pin();
       }
     } else if (__ballot(fit && n != M) == 0ull) {
@@ -544,10 +560,12 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     const double total = smoothed ? s1 + at : s1;
     bool bad_out = !(total > kCancelGuard * s1);  // the tail cancels against the sum of all exponentials
     const double tail_ratio = smoothed ? (double)(S - n) + ar : (double)S;
-    const double lg = log_tab(t == 1 ? s2 : div_fast(tail_ratio, total), lt);
+    bool lwm = false;  // weights mode: lane 0's logarithm is log(total) itself (psis.py:158), the second sum is not looked at
+    if constexpr (!STREAM) lwm = Q.ws_w != nullptr;
+    const double lg = log_tab(t == 1 ? (lwm ? 1.0 : s2) : (lwm ? total : div_fast(tail_ratio, total)), lt);
     const double lg1 = dpp_mov_u<0xB1, 0xF>(lg);  // lane t = 0 receives lane 1's logarithm
     const double loo = lg - m;
-    const double lppd = (lg1 - R) + ((-mn) - Q.log_S);
+    const double lppd = lwm ? 0.0 : (lg1 - R) + ((-mn) - Q.log_S);
     if (!(total > 1e-280) || !isfinite(loo) || !isfinite(lppd)) bad_out = true;
     const unsigned long long badm = __ballot(bad);
     const bool slow = (fit && ((badm >> (lane & 48)) & 0xFFFFull) != 0ull) || bad_out;
@@ -574,6 +592,11 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
         if (pd) pd[r] = fit ? khat : INF;
         if (pl) pl[r] = scale * loo;
         if (pp) pp[r] = lppd;
+      }
+      if (lwm) {  // for the output pass: log of the normaliser, tail draws to patch (-1: the general kernel writes this row)
+        double* sc_out = const_cast<double*>(Q.ws_s) + sc;
+        sc_out[2] = lg;
+        sc_out[5] = slow ? -1.0 : (smoothed ? (double)n : 0.0);
       }
     }
   };

@@ -55,6 +55,8 @@ inline const char* dtype_name(int dtype) { return dtype == PLA_F64 ? "double" : 
 // general kernel (pla_rows.h): every row / the rows a fast path declined (device list)
 hipError_t launch_general(const RowsParams& p, int dtype, bool lw, hipStream_t stream);
 hipError_t launch_slow_rows(const RowsParams& p, int dtype, bool lw, hipStream_t stream, int block = 256);
+// output pass of the split weights pass for long rows (pla_lwout.h): behind the selection and the fit kernel
+hipError_t launch_lw_output(const RowsParams& p, int dtype, hipStream_t stream);
 size_t general_smem_bytes(const RowsParams& p);
 
 // fit kernels of the split pass (pla_fit.h)

@@ -395,6 +395,61 @@ def test_weights_device_tensors_full_size(eng):
     close(lw.cpu().numpy()[idx], ref_lw, what="lw")
 
 
+def test_long_row_weights_take_the_split_pass(eng):
+    """psislw on device-resident rows longer than the registers (S > 4096, tails the fit kernel takes): selection kernel ->
+    fit kernel -> output kernel (csrc/pla_lwout.h), in blocks of 2^17 observations.  Rows on both sides of the block boundary
+    equal a separate call over just those rows bit for bit, sampled rows equal the oracle (tied tail draws as multisets),
+    every row is normalised, k-hat equals the LOO pass's, and the call is reproducible."""
+    import torch
+
+    S, N = 4352, (1 << 17) + 37
+    M = orc.tail_count(S, 1.0)
+    ll = torch.empty((N, S), dtype=torch.float32, device="cuda")
+    eng.fill_synthetic(ll, seed=0x5EED0021, k_lo=0.05, k_hi=1.2)
+    ll[5, : S // 2] = torch.round(ll[5, : S // 2] * 8.0) / 8.0          # ties, also inside the tail
+    ll[(1 << 17) + 3, 100:2000] = torch.round(ll[(1 << 17) + 3, 100:2000] * 4.0) / 4.0
+    ll[9, 17] = float("nan")                                            # rows for the general kernel
+    ll[(1 << 17) - 1] *= 300.0                                         # (a range above 690 nats)
+    logw = -ll
+    lw, k = eng.importance_weights(logw, M, "psis")
+    assert "lw_output_kernel" in eng.last_kernels(), eng.last_kernels()
+    lw_b, k_b = eng.importance_weights(logw, M, "psis")
+    torch.cuda.synchronize()
+
+    def same_rows(a, b):
+        # equal tail draws may swap their quantiles between two runs (a counter hands out their ranks: f32 rows tie now and
+        # then): such rows must hold the same multiset; nothing else may differ
+        same = (a == b) | (torch.isnan(a) & torch.isnan(b))
+        bad = (~same).any(dim=1).nonzero().flatten()
+        assert bad.numel() <= 0.05 * a.shape[0], bad.numel()
+        if bad.numel():
+            sa, sb = torch.sort(a[bad], dim=1).values, torch.sort(b[bad], dim=1).values
+            assert torch.equal(sa.nan_to_num(9.0), sb.nan_to_num(9.0))
+
+    same_rows(lw, lw_b)
+    assert torch.equal(k.nan_to_num(7.0), k_b.nan_to_num(7.0))
+    lo, hi = (1 << 17) - 40, (1 << 17) + 37
+    part, k_part = eng.importance_weights(logw[lo:hi].clone(), M, "psis")
+    same_rows(lw[lo:hi], part)
+    assert torch.equal(k[lo:hi].nan_to_num(7.0), k_part.nan_to_num(7.0))
+    res = eng.psis_loo(ll, M, "psis", 1.0, 0.7)
+    fin = torch.isfinite(k)
+    np.testing.assert_allclose(k[fin].cpu().numpy(), res["diag"][fin].cpu().numpy(), rtol=1e-9)
+    good = ~torch.isnan(lw).any(dim=1)
+    assert int((~good).sum()) == 1                                      # (the NaN row)
+    sums = torch.exp(lw[good].double()).sum(dim=1).cpu().numpy()
+    np.testing.assert_allclose(sums, 1.0, rtol=2e-5)                    # (f32 outputs)
+    idx = np.unique(np.concatenate([np.arange(0, N, 2999), [5, 9, (1 << 17) - 1, 1 << 17, (1 << 17) + 3, N - 1]]))
+    ref_lw, ref_k = orc.psislw(logw[idx].cpu().numpy().astype(np.float64), 1.0)
+    got = lw.cpu().numpy()[idx].astype(np.float64)
+    llh = ll.cpu().numpy()[idx]
+    for i in range(len(idx)):
+        if has_tail_ties(llh[i], M):
+            got[i], ref_lw[i] = np.sort(got[i]), np.sort(ref_lw[i])
+    close(k.cpu().numpy()[idx], ref_k, what="khat")
+    close(got.astype(np.float32), ref_lw.astype(np.float32), rtol=3e-7, atol=2e-7, what="lw (f32 output)")
+
+
 @pytest.mark.parametrize("S,N,reff,dt", [(8000, 150, 1.0, np.float64), (20000, 60, 1.0, np.float32),
                                          (4096 + 256, 40, 1.0, np.float64), (12288, 30, 0.5, np.float64),
                                          (4000, 80, 0.3, np.float64), (2000, 64, 0.35, np.float64)])

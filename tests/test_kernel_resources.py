@@ -43,6 +43,11 @@ KERNELS = {
     "col_select_kernel": 81920,
     "waic_col_kernelId": 81920,
     "e_loo_quantile_kernelIdLi512": 81920,      # 512 threads per observation: the shapes / rows the wave kernel does not take
+    # split weights pass of long rows (round 4): the selection kernel with weights-mode signs, the output kernel (three workgroups per CU)
+    "wave_loo_chunked_kernelIfLi4ENS_7CapsMidELb1ELb1": 81920,
+    "wave_loo_chunked_kernelIdLi2ENS_7CapsMidELb1ELb1": 81920,
+    "lw_output_kernelIf": 54613,
+    "lw_output_kernelId": 54613,
 }
 
 

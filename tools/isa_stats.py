@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 KERNEL_UNITS = ["pla_k_general.hip", "pla_k_wave_f64.hip", "pla_k_wave_f32.hip", "pla_k_chunked_f64.hip", "pla_k_chunked_f32.hip",
-                "pla_k_fit.hip", "pla_k_waic.hip", "pla_k_col.hip", "pla_k_eloo.hip"]
+                "pla_k_fit.hip", "pla_k_lwout.hip", "pla_k_waic.hip", "pla_k_col.hip", "pla_k_eloo.hip"]
 
 
 def compile_isa(extra=(), out="/tmp/pla_isa.s", units=None):
@@ -50,6 +50,8 @@ def unit_of(pat):
         return ["pla_k_wave_f32.hip" if f32 else "pla_k_wave_f64.hip"]
     if pat.startswith("fit_rows"):
         return ["pla_k_fit.hip"]
+    if pat.startswith("lw_output"):
+        return ["pla_k_lwout.hip"]
     if pat.startswith(("col_", "tile_")):
         return ["pla_k_col.hip"]
     if pat.startswith("e_loo"):
