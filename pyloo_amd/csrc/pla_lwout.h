@@ -176,8 +176,11 @@ __global__ __launch_bounds__(kWave * kLwoWaves, 3) void lw_output_kernel(LwOutPa
           }
         }
       }
+#ifndef PLA_LWO_ABLATE
+#define PLA_LWO_ABLATE 0  // timing experiments: 2 = the tail draws are collected but not patched
+#endif
       if (ntail != 0u) {  // (wave-uniform)
-        patch(ntail < (unsigned)kLwoTail ? ntail : (unsigned)kLwoTail);
+        if (!(PLA_LWO_ABLATE & 2)) patch(ntail < (unsigned)kLwoTail ? ntail : (unsigned)kLwoTail);
         ntail = 0u;
       }
     };
