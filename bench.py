@@ -311,8 +311,9 @@ def main():
             "frac": alg_bytes / (first_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         }
 
-    if not args.no_cpu:
-        # ---- CPU baseline + parity on a bounded sample of the same matrix (rank 0 only) -------
+    if not args.no_cpu and world == 1:
+        # ---- CPU baseline + parity on a bounded sample of the same matrix (one GPU only: at N > 1 the other ranks would wait
+        #      at the closing barrier for it, and the baseline is the same number) -------
         from oracle import psis_oracle as orc
 
         chunk = max(16, 512 * 4000 // S)

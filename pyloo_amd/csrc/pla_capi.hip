@@ -187,9 +187,6 @@ struct EngineCall {
   EngineCall(pla_engine* e_, hipStream_t s_) : lock(e_->mu), e(e_), s(s_), ordered(false) {
     g_frozen = e->frozen;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-#if defined(PLA_NO_ORDER_EVENT)
-    return;
-#endif
     if (hipSetDevice(e->device) != hipSuccess || !e->order_event) return;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
       (void)hipGetLastError();

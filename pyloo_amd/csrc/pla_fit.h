@@ -611,17 +611,6 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     // them: groups of waves 1 and 3 went missing.  tests/test_kernel_resources.py holds this kernel to zero such spills.)
     const auto wait_for = [&](int c) -> bool {
       asm volatile("" : "+v"(c));
-#if defined(PLA_OLD_POLL)
-      unsigned looks = 0;
-      while (__hip_atomic_load(Q.done + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-        if (++looks > 2000000u) {
-          __hip_atomic_store(Q.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          return false;
-        }
-        __builtin_amdgcn_s_sleep(PLA_STREAM_SLEEP);
-      }
-      return true;
-#endif
       // (done[c] counts the rows of chunk c that have been handed over: pla_fast.h, kQueueUnit)
       const int64_t left = Q.n_obs - (int64_t)c * kQueueChunk;
       unsigned need = left < kQueueChunk ? (unsigned)left : (unsigned)kQueueChunk;
