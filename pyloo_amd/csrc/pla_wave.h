@@ -477,13 +477,65 @@ __device__ __forceinline__ void count_if(int& cnt, float a, float b) {
 // (Weights mode rewrites its pads late -- doing it early costs that kernel registers it does not have -- so there the
 // slots past the row still hold copies of the lane's first draws and are counted with them: exact to 96 / 4096 at S = 4000,
 // cruder for rows much shorter than the register block; the candidate count after the sweep is exact either way.)
+// four slots at a time, counted on the SCALAR side: four compares into four scalar masks, their population counts and the
+// running sum are scalar instructions -- one vector operation per slot instead of two (the pass is bound by vector issue), and
+// the wave-uniform total needs no reduction across the lanes.  (Left to the compiler, the 64 masks of the unrolled count are all
+// computed first and spilled: hence four per block, written out.)
+#ifndef PLA_COUNT_SALU
+#define PLA_COUNT_SALU 1
+#endif
+template <bool GE>
+__device__ __forceinline__ void count4_scalar(int& cnt, double a0, double a1, double a2, double a3, double b) {
+  unsigned long long m0, m1, m2, m3;
+  int c0, c1, c2, c3;
+  if constexpr (GE)
+    asm volatile("v_cmp_ge_f64 %1, %9, %13\n\tv_cmp_ge_f64 %2, %10, %13\n\tv_cmp_ge_f64 %3, %11, %13\n\tv_cmp_ge_f64 %4, %12, %13\n\t"
+                 "s_bcnt1_i32_b64 %5, %1\n\ts_bcnt1_i32_b64 %6, %2\n\ts_bcnt1_i32_b64 %7, %3\n\ts_bcnt1_i32_b64 %8, %4\n\t"
+                 "s_add_i32 %5, %5, %6\n\ts_add_i32 %7, %7, %8\n\ts_add_i32 %0, %0, %5\n\ts_add_i32 %0, %0, %7"
+                 : "+s"(cnt), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3)
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b)
+                 : "scc");
+  else
+    asm volatile("v_cmp_le_f64 %1, %9, %13\n\tv_cmp_le_f64 %2, %10, %13\n\tv_cmp_le_f64 %3, %11, %13\n\tv_cmp_le_f64 %4, %12, %13\n\t"
+                 "s_bcnt1_i32_b64 %5, %1\n\ts_bcnt1_i32_b64 %6, %2\n\ts_bcnt1_i32_b64 %7, %3\n\ts_bcnt1_i32_b64 %8, %4\n\t"
+                 "s_add_i32 %5, %5, %6\n\ts_add_i32 %7, %7, %8\n\ts_add_i32 %0, %0, %5\n\ts_add_i32 %0, %0, %7"
+                 : "+s"(cnt), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3)
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b)
+                 : "scc");
+}
+template <bool GE>
+__device__ __forceinline__ void count4_scalar(int& cnt, float a0, float a1, float a2, float a3, float b) {
+  unsigned long long m0, m1, m2, m3;
+  int c0, c1, c2, c3;
+  if constexpr (GE)
+    asm volatile("v_cmp_ge_f32 %1, %9, %13\n\tv_cmp_ge_f32 %2, %10, %13\n\tv_cmp_ge_f32 %3, %11, %13\n\tv_cmp_ge_f32 %4, %12, %13\n\t"
+                 "s_bcnt1_i32_b64 %5, %1\n\ts_bcnt1_i32_b64 %6, %2\n\ts_bcnt1_i32_b64 %7, %3\n\ts_bcnt1_i32_b64 %8, %4\n\t"
+                 "s_add_i32 %5, %5, %6\n\ts_add_i32 %7, %7, %8\n\ts_add_i32 %0, %0, %5\n\ts_add_i32 %0, %0, %7"
+                 : "+s"(cnt), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3)
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b)
+                 : "scc");
+  else
+    asm volatile("v_cmp_le_f32 %1, %9, %13\n\tv_cmp_le_f32 %2, %10, %13\n\tv_cmp_le_f32 %3, %11, %13\n\tv_cmp_le_f32 %4, %12, %13\n\t"
+                 "s_bcnt1_i32_b64 %5, %1\n\ts_bcnt1_i32_b64 %6, %2\n\ts_bcnt1_i32_b64 %7, %3\n\ts_bcnt1_i32_b64 %8, %4\n\t"
+                 "s_add_i32 %5, %5, %6\n\ts_add_i32 %7, %7, %8\n\ts_add_i32 %0, %0, %5\n\ts_add_i32 %0, %0, %7"
+                 : "+s"(cnt), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3)
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b)
+                 : "scc");
+}
 template <typename T, bool LW>
 __device__ __forceinline__ int count_above(const T (&v)[kWaveSlots], T thr) {
-  int cnt = 0;  // per lane
   asm volatile("" : "+v"(thr));
+#if PLA_COUNT_SALU
+  int total = 0;  // wave-uniform, in a scalar register
+#pragma unroll
+  for (int i = 0; i < kWaveSlots; i += 4) count4_scalar<LW>(total, v[i], v[i + 1], v[i + 2], v[i + 3], thr);
+  return total;
+#else
+  int cnt = 0;  // per lane
 #pragma unroll
   for (int i = 0; i < kWaveSlots; ++i) count_if<LW>(cnt, v[i], thr);
   return wave_sum_int(cnt);
+#endif
 }
 // The speculative threshold comes from an order statistic of per-lane GROUP maxima over a sample of the row: a biased
 // quantile estimate when the draws of a group are dependent (autocorrelated MCMC output: the sample is made of 128-draw
