@@ -395,7 +395,7 @@ def test_weights_device_tensors_full_size(eng):
     close(lw.cpu().numpy()[idx], ref_lw, what="lw")
 
 
-def test_long_row_weights_take_the_split_pass(eng):
+def test_long_row_weights_take_the_split_pass(eng, monkeypatch):
     """psislw on device-resident rows longer than the registers (S > 4096, tails the fit kernel takes): selection kernel ->
     fit kernel -> output kernel (csrc/pla_lwout.h), in blocks of 2^17 observations.  Rows on both sides of the block boundary
     equal a separate call over just those rows bit for bit, sampled rows equal the oracle (tied tail draws as multisets),
@@ -432,6 +432,19 @@ def test_long_row_weights_take_the_split_pass(eng):
     part, k_part = eng.importance_weights(logw[lo:hi].clone(), M, "psis")
     same_rows(lw[lo:hi], part)
     assert torch.equal(k[lo:hi].nan_to_num(7.0), k_part.nan_to_num(7.0))
+    # EVERY row against the general kernel (all 26 M patched positions: the output kernel writes a draw's smoothed weight right
+    # behind the row's own store of that position, without waiting for it -- a patch that lost that race would show here)
+    monkeypatch.setenv("PLA_FORCE_PATH", "1")
+    lw_g, k_g = eng.importance_weights(logw, M, "psis")
+    monkeypatch.delenv("PLA_FORCE_PATH")
+    assert "lw_output_kernel" not in eng.last_kernels()
+    near = torch.isclose(lw, lw_g, rtol=3e-7, atol=2e-7, equal_nan=True)
+    off = (~near).any(dim=1).nonzero().flatten()
+    assert off.numel() <= 0.05 * N, off.numel()
+    if off.numel():  # (tied tail draws: the same multiset of weights)
+        sa, sb = torch.sort(lw[off], dim=1).values, torch.sort(lw_g[off], dim=1).values
+        assert bool(torch.isclose(sa, sb, rtol=3e-7, atol=2e-7, equal_nan=True).all())
+    del lw_g
     res = eng.psis_loo(ll, M, "psis", 1.0, 0.7)
     fin = torch.isfinite(k)
     np.testing.assert_allclose(k[fin].cpu().numpy(), res["diag"][fin].cpu().numpy(), rtol=1e-9)
