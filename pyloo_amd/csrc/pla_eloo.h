@@ -336,7 +336,11 @@ __global__ __launch_bounds__(256) void e_loo_wave_kernel(ELooParams P) {
     double xlo = fx[0], xhi = fx[0], qlo = fx[0] * fx[0], qhi = qlo;
     bool three_x = false, three_q = false;
     double xdev = 0.0, qdev = 0.0;
-    const auto elem = [&](double x, double a, double b, bool valid) {
+    // ALL (every step but the last): the vector lies inside the row in every lane -- none of the selects that turn a draw past
+    // the end of the row into one that changes nothing (a fifth of the pass's vector instructions)
+    const auto elem = [&](double x, double a, double b, bool valid_in, auto all_c) {
+      constexpr bool ALL = decltype(all_c)::value;
+      const bool valid = ALL ? true : valid_in;
       if (!valid) {  // past the end of the row: a draw that changes nothing
         x = xlo;
         a = -INF;
@@ -392,16 +396,25 @@ __global__ __launch_bounds__(256) void e_loo_wave_kernel(ELooParams P) {
       qdev = fmax(qdev, fabs(q - q0));
     };
 #pragma unroll 1
-    for (int st = 0; st < steps; ++st) {
+    for (int st = 0; st < steps - 1; ++st) {
       double vx[VEC], vw[VEC], vl[VEC];
       unpack(cx, vx);
       unpack(cw, vw);
       if constexpr (OWN) unpack(cl, vl);
       cx = nx; cw = nwv; cl = nl;
       if (st + 2 < steps) load3(st + 2, nx, nwv, nl);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) elem(vx[e], vw[e], OWN ? vl[e] : vw[e], true, std::true_type{});
+    }
+    {  // the last step: some lanes' vectors lie past the end of the row
+      const int st = steps - 1;
+      double vx[VEC], vw[VEC], vl[VEC];
+      unpack(cx, vx);
+      unpack(cw, vw);
+      if constexpr (OWN) unpack(cl, vl);
       const bool valid = (st * kWave + lane) * VEC < S;  // (S is a multiple of VEC: a vector is inside the row or past it)
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) elem(vx[e], vw[e], OWN ? vl[e] : vw[e], valid);
+      for (int e = 0; e < VEC; ++e) elem(vx[e], vw[e], OWN ? vl[e] : vw[e], valid, std::false_type{});
     }
     // ---- across the lanes ----------------------------------------------------------------------------------------
     double SA, SB, SC, SD;
@@ -460,9 +473,23 @@ __global__ __launch_bounds__(256) void e_loo_wave_kernel(ELooParams P) {
       wave_all4<R_SUM>(a1, a2, a3, a4, c1l, c1r, c2l, c2r);
       n_close_r = wave_all<R_SUM>(cr);
     }
-    if (lane == 0)
-      e_loo_finish(P, r, n_tail, 0u, SA, SB, SC, SD, x0, q0, XD, QD, xmn, xmx, qmn, qmx, two_x, two_q, (double)S, n_close_r, c1l, c1r,
+    if (lane == 0) {
+      // (what the end of a row needs of the launch's arguments -- five output pointers, the tail length and the constants derived
+      // from it -- is read from the argument block HERE, behind an opaque pointer: hoisted above the row loop it sat in scalar
+      // registers the loop does not have, 19 of them spilled into vector lanes -- the form that came back wrong in round 4's fit
+      // kernel; tests/test_kernel_resources.py holds this kernel to none)
+#if defined(__HIP_DEVICE_COMPILE__)
+      typedef const __attribute__((address_space(4))) ELooParams* ArgPtr;
+      ArgPtr qp = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(qp));
+      const ELooParams Pl = *qp;
+#else
+      const ELooParams& Pl = P;
+#endif
+      const int nt = S < Pl.tail_len ? S : Pl.tail_len;
+      e_loo_finish(Pl, r, nt, 0u, SA, SB, SC, SD, x0, q0, XD, QD, xmn, xmx, qmn, qmx, two_x, two_q, (double)S, n_close_r, c1l, c1r,
                    c2l, c2r);
+    }
   }
 }
 

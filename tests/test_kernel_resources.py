@@ -68,11 +68,26 @@ def test_row_kernels_do_not_spill(isa_lines):
         name, total, _, res = isa_stats.kernel_stats(lines, pat)
         assert res.get("ScratchSize", 0) == 0, (name, res)
         # (the fused chunked kernels keep a few hoisted scalars in vector lanes: no scratch next to them, checked above)
-        allowed = 4 if pat.endswith("ELb0ELb1") else 1 if pat.endswith("ELb0ELb0") else 24 if pat.startswith("e_loo") else 0  # (e_loo: lane masks of its many flags)
+        allowed = 4 if pat.endswith("ELb0ELb1") else 1 if pat.endswith("ELb0ELb0") else 8 if pat.startswith("e_loo_quantile_kernel") else 0
         assert total.get("v_writelane_b32", 0) <= allowed, (name, dict(total))
         assert not any(k.startswith("scratch_") for k in total), (name, dict(total))
         assert res.get("NumVgprs", 0) <= 256 and res.get("Occupancy", 0) >= 1, (name, res)
         assert res.get("LDSByteSize", 0) <= lds_limit, (name, res)  # two (or the stated number of) workgroups per CU (160 KB LDS)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+def test_no_scalar_spill_is_written_under_an_execution_mask(isa_lines):
+    """EVERY kernel of the library: a scalar register spilled into a vector lane (v_writelane) inside an exec-masked region is
+    not written by a wave whose lanes all skip that region (s_cbranch_execz), and the v_readlane behind it returns garbage --
+    how round 4's streamed fit kernel lost the outputs of whole groups.  Spills in uniform control flow (the general kernels
+    keep a dozen loop invariants that way) are harmless and allowed."""
+    import isa_stats
+
+    kernels = isa_stats.all_kernels(isa_lines)
+    assert len(kernels) >= 90, len(kernels)
+    for k in kernels:
+        bad = isa_stats.masked_spills(isa_lines, k[2:])
+        assert not bad, (k, bad[:4])
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")

@@ -95,6 +95,35 @@ def kernel_stats(lines, pat):
     return lines[start].split(":")[0], total, phases, res
 
 
+def masked_spills(lines, pat):
+    """SGPR spills of one kernel that are WRITTEN inside an exec-masked region (between an s_*_saveexec_b64 into a scalar pair and
+    the s_or_b64 exec that restores it).  A wave whose lanes all skip such a region -- the compiler jumps over it with
+    s_cbranch_execz -- never executes the v_writelane, and the v_readlane behind the region then returns whatever the vector
+    register held: the failure of round 4's streamed fit kernel.  Spills written in uniform control flow are harmless."""
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + re.escape(pat) + r"\w*:", l))
+    end = next(i for i in range(start, len(lines)) if re.match(r"^\.Lfunc_end\d+:", lines[i]))
+    open_regions, bad = [], []
+    for l in lines[start:end]:
+        t = l.strip()
+        m = re.match(r"s_(?:and|andn2|or|xor|nand|nor|xnor)_saveexec_b64 (s\[\d+:\d+\]|vcc)", t)
+        if m:
+            if m.group(1) not in open_regions:
+                open_regions.append(m.group(1))
+            continue
+        m = re.match(r"s_or_b64 exec, exec, (s\[\d+:\d+\]|vcc)", t)
+        if m and m.group(1) in open_regions:
+            open_regions.remove(m.group(1))
+            continue
+        if t.startswith("v_writelane_b32") and open_regions:
+            bad.append(t)
+    return bad
+
+
+def all_kernels(lines):
+    names = [m.group(1) for l in lines for m in [re.match(r"^(_Z\w+):\s*(;.*)?$", l)] if m and "pla" in m.group(1)]
+    return [n for n in names if any(l.strip() == ".amdhsa_kernel " + n for l in lines)]
+
+
 def demangle(names):
     """c++filt over the mangled kernel names (the LLVM copy under /opt/rocm when binutils is absent)."""
     for tool in ("c++filt", "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"):
