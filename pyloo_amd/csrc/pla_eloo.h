@@ -1145,15 +1145,18 @@ __global__ __launch_bounds__(256, 2) void e_loo_quantile_wave_kernel(EQuantParam
     bool bad = false;
     unsigned one = 1u;
     asm volatile("" : "+v"(one));
-#pragma unroll 1
-    for (int q0 = 0; q0 < NQ; q0 += kQWBatch) {
+    // ALL: every vector of the batch lies inside the row in every lane (all batches but the last one or two) -- no selects that
+    // turn a slot past the end of the row into a draw that changes nothing, no branches around the two histogram atomics: a
+    // quarter of the trip's vector instructions
+    const auto batch = [&](const int q0, auto all_c) {
+      constexpr bool ALL = decltype(all_c)::value;
       double a[kQWBatch][VEC], x[kQWBatch][VEC];
       double bm = -INF;
 #pragma unroll
       for (int u = 0; u < kQWBatch; ++u) {
         unpack(tx[u], x[u]);
         unpack(tw[u], a[u]);
-        const bool valid = q0 + u < nval;
+        const bool valid = ALL ? true : q0 + u < nval;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           bad |= valid & ((a[u][e] != a[u][e]) | !(fabs(x[u][e]) < INF));
@@ -1175,7 +1178,7 @@ __global__ __launch_bounds__(256, 2) void e_loo_quantile_wave_kernel(EQuantParam
       unsigned packed[kQWBatch * VEC / 2];
 #pragma unroll
       for (int u = 0; u < kQWBatch; ++u) {
-        const bool valid = q0 + u < nval;
+        const bool valid = ALL ? true : q0 + u < nval;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           const double w = valid ? wexp(a[u][e] - mlw) : 0.0;
@@ -1199,6 +1202,16 @@ __global__ __launch_bounds__(256, 2) void e_loo_quantile_wave_kernel(EQuantParam
         unsigned* dst = reinterpret_cast<unsigned*>(&sm.bins[lane * kRow + q0 * VEC]);
 #pragma unroll
         for (int k = 0; k < kQWBatch * VEC / 2; k += 2) *reinterpret_cast<uint2*>(dst + k) = make_uint2(packed[k], packed[k + 1]);
+      }
+    };
+#pragma unroll 1
+    for (int q0 = 0; q0 < NQ; q0 += kQWBatch) {
+      // (f64 rows only: the f32 kernel, 32 draws per lane and batch, has no registers for a second copy of the batch's code)
+      if constexpr (VEC == 2) {
+        if (q0 + kQWBatch <= qfull) batch(q0, std::true_type{});  // (wave-uniform)
+        else batch(q0, std::false_type{});
+      } else {
+        batch(q0, std::false_type{});
       }
     }
     double xmax, nxmin;
