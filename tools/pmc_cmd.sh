@@ -1,6 +1,7 @@
 #!/bin/bash
 # Issue counters per unit of work of every pla:: kernel of any python command of this repo:
 #   UNITS=200000 bash tools/pmc_cmd.sh tools/bench_e_loo.py
+#   UNITS=125000 bash tools/pmc_cmd.sh bench.py --config C5 --steps 1 --warmup 1 --no-cpu
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 UNITS=${UNITS:-200000}
 cd /tmp && export TMPDIR=/tmp

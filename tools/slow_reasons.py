@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Why rows leave the fast selection path, per kind of row order (profiling build with PLA_WAVE_ABLATE=1):
-   PYLOO_AMD_LIB=.../libpyloo_amd_ablate.so PLA_PRINT_REASONS=1 python tools/slow_reasons.py"""
+   python -m pyloo_amd.build --alt=ablate -DPLA_WAVE_ABLATE=1 -DPLA_EXPERIMENT && PYLOO_AMD_LIB=$PWD/pyloo_amd/lib/alt_ablate.so PLA_PRINT_REASONS=1 python tools/slow_reasons.py"""
 import os
 import sys
 import zlib
