@@ -952,24 +952,24 @@ int pla_importance_weights(pla_engine* eng, const void* logw, int dtype, int64_t
     p.diag = diag;
     p.lw_out = lw_out;
     // Rows longer than the registers (S > 4096) with tails the fit kernel takes: the split weights pass (selection kernel -> fit
-    // kernel -> output kernel, csrc/pla_lwout.h) needs the hand-over buffers -- tail x, smoothed weights by rank, scalars -- for
-    // the rows of one launch, so such calls run in blocks of 2^17 observations (0.94 GB at 448-value tails).  No room: the
+    // kernel -> output kernel, csrc/pla_lwout.h) needs the hand-over buffers -- the tail's x and eight scalars per observation -- for
+    // the rows of one launch, so such calls run in blocks of 2^17 observations (0.48 GB at 448-value tails).  No room: the
     // fused weights kernel, which needs none.
     int64_t block = n_obs;
     if (method == PLA_PSIS && n_draws > 4096 && tail_count <= 448 && stride_draw == 1 && n_obs > 0) {
       const int64_t kLwBlock = (int64_t)1 << 17;
       block = n_obs < kLwBlock ? n_obs : kLwBlock;
       const int stride = (int)((tail_count + 63) & ~(int64_t)63);
-      rc = grow(&eng->d_ws, &eng->d_ws_bytes, (size_t)block * (size_t)(2 * stride + 8) * sizeof(double));
+      rc = grow(&eng->d_ws, &eng->d_ws_bytes, (size_t)block * (size_t)(stride + 8) * sizeof(double));
       if (rc == PLA_ERR_NOMEM) {
         block = n_obs;
       } else {
         if (rc) return rc;
         p.ws_y = (double*)eng->d_ws;
-        p.ws_w = p.ws_y + (size_t)block * stride;
-        p.ws_s = p.ws_w + (size_t)block * stride;
+        p.ws_s = p.ws_y + (size_t)block * stride;
         p.ws_stride = stride;
         p.ws_sstride = 8;
+        p.lw_split = true;
       }
     }
     TimedLaunch t(eng, s);
@@ -998,14 +998,14 @@ int pla_importance_weights(pla_engine* eng, const void* logw, int dtype, int64_t
   if (rc) return rc;
   if (method == PLA_PSIS && n_draws > 4096 && tail_count <= 448) {  // (the split weights pass of long rows, as on the device path)
     const int stride = (int)((tail_count + 63) & ~(int64_t)63);
-    rc = grow(&eng->d_ws, &eng->d_ws_bytes, (size_t)rows_per_chunk * (size_t)(2 * stride + 8) * sizeof(double));
+    rc = grow(&eng->d_ws, &eng->d_ws_bytes, (size_t)rows_per_chunk * (size_t)(stride + 8) * sizeof(double));
     if (rc && rc != PLA_ERR_NOMEM) return rc;
     if (!rc) {
       p.ws_y = (double*)eng->d_ws;
-      p.ws_w = p.ws_y + (size_t)rows_per_chunk * stride;
-      p.ws_s = p.ws_w + (size_t)rows_per_chunk * stride;
+      p.ws_s = p.ws_y + (size_t)rows_per_chunk * stride;
       p.ws_stride = stride;
       p.ws_sstride = 8;
+      p.lw_split = true;
     }
   }
   {

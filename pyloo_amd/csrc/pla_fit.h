@@ -84,10 +84,11 @@ struct FitParams {
   unsigned patience = 0, patience_start = 0;
   unsigned long long* gave_up_total = nullptr;  // engine statistics: passes in which the streamed fit gave up (plain fit kernel, leftovers)
   // WEIGHTS mode (psislw of rows longer than the registers: selection kernel -> this kernel -> lw_output_kernel, pla_lwout.h):
-  // non-null = this kernel writes, per observation, the tail's x back to ws_y SORTED (descending rank p at [p]), the smoothed
-  // weight of rank p to ws_w[p], and into the scalars log(sum of the smoothed weights) at [2] and the number of tail draws to
-  // patch at [5] (0: nothing was smoothed; -1: on the list for the general kernel); k-hat goes to `diag` as in LOO mode
-  double* ws_w = nullptr;
+  // this kernel writes, per observation, the tail's x back to ws_y SORTED (descending rank p at [p]) and into the scalars
+  // log(sum of the smoothed weights) at [2], k-hat at [3], sigma / k-hat at [6], e_cut - sigma / k-hat at [7] -- what the smoothed
+  // weight of a rank is evaluated from -- and the number of tail draws to patch at [5] (0: nothing was smoothed; -1: on the
+  // list for the general kernel); k-hat goes to `diag` as in LOO mode
+  bool lw_mode = false;
 };
 
 // 16 bytes of the hand-over.  STREAM: an agent-scope (sc1) load straight from memory -- the bytes were written, by the kernel
@@ -226,6 +227,17 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     int t = t_lane;
     if constexpr (DYN) asm volatile("" : "+v"(t));
     PLA_PHASE(20);
+    // (weights mode: asked of the kernel's argument block once per group, behind an opaque pointer -- as a loop invariant its
+    // tests were hoisted above the group loop into scalar registers the kernel does not have: four spilled into vector lanes)
+    bool lwm = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (!STREAM) {
+      typedef const __attribute__((address_space(4))) FitParams* ArgPtrG;
+      ArgPtrG qa = (ArgPtrG)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(qa));
+      lwm = qa->lw_mode;
+    }
+#endif
     const int64_t r0 = grp * 4 + rho;
     const bool inrange = r0 < Q.n_obs;
     const int64_t r = inrange ? r0 : Q.n_obs - 1;
@@ -290,7 +302,7 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
       for (int it = 0; it < 8 * K && unsorted(); ++it) sort_round();
     PLA_PHASE(23);
       if constexpr (!STREAM) {
-        if (Q.ws_w && handled && fit) {  // weights mode: the output pass ranks the row's tail draws against this (pla_lwout.h)
+        if (lwm && handled && fit) {  // weights mode: the output pass ranks the row's tail draws against this (pla_lwout.h)
           double* ysorted = const_cast<double*>(Q.ws_y) + y0;
 #pragma unroll
           for (int i = 0; i < 2 * NQ; ++i) *reinterpret_cast<double2*>(ysorted + K * t + 2 * i) = yv[i];
@@ -507,13 +519,12 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     if (smoothed && (!(sigma > 0.0) || fabs(khat) < kEps)) bad = true;
     const double coef_s = sigma / khat, off = e_cut - coef_s;
     double acc_t = 0.0, acc_r = 0.0;
-    const auto smooth = [&](int j, double l1, double yj) -> double {
+    const auto smooth = [&](int j, double l1, double yj) {
       const double ez = exp_tab(fmin(-khat * l1, 700.0), tab);
       const double wj = fmin(fma(ez, coef_s, off), 1.0);  // exp(log(q + e_cut)) clipped at 0 (psis.py:155,157)
       const double ej = yj + e_cut;
       acc_t += (j < n) ? wj - ej : 0.0;
       acc_r += (j < n) ? div_fast(wj, ej) : 0.0;
-      return wj;
     };
     // (the sums are pinned every few elements: left alone, the scheduler starts every element at once and spills)
     const auto pin = [&]() { asm volatile("" : "+v"(acc_t), "+v"(acc_r)); };
@@ -528,11 +539,8 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
           asm volatile("");
           if (n != M) l1 = make_double2(log_fast(1.0 - ((double)(n - 1 - p) + 0.5) * rn), log_fast(1.0 - ((double)(n - 2 - p) + 0.5) * rn));
         }
-        const double w0 = smooth(p, l1.x, yv[i].x);
-        const double w1 = smooth(p + 1, l1.y, yv[i].y);
-        if constexpr (!STREAM) {
-          if (Q.ws_w && handled && smoothed) *reinterpret_cast<double2*>(Q.ws_w + y0 + p) = make_double2(w0, w1);  // (weights mode: rank p's smoothed weight)
-        }
+        smooth(p, l1.x, yv[i].x);
+        smooth(p + 1, l1.y, yv[i].y);
         if ((i % PLA_FIT_PIN) == PLA_FIT_PIN - 1) pin();
       }
     } else if (__ballot(fit && n != M) == 0ull) {
@@ -560,8 +568,7 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     const double total = smoothed ? s1 + at : s1;
     bool bad_out = !(total > kCancelGuard * s1);  // the tail cancels against the sum of all exponentials
     const double tail_ratio = smoothed ? (double)(S - n) + ar : (double)S;
-    bool lwm = false;  // weights mode: lane 0's logarithm is log(total) itself (psis.py:158), the second sum is not looked at
-    if constexpr (!STREAM) lwm = Q.ws_w != nullptr;
+    // (weights mode: lane 0's logarithm is log(total) itself (psis.py:158), the second sum is not looked at)
     const double lg = log_tab(t == 1 ? (lwm ? 1.0 : s2) : (lwm ? total : div_fast(tail_ratio, total)), lt);
     const double lg1 = dpp_mov_u<0xB1, 0xF>(lg);  // lane t = 0 receives lane 1's logarithm
     const double loo = lg - m;
@@ -578,12 +585,14 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
     unsigned* plist = Q.slow_list;
     unsigned sbase = Q.slow_base;
     double scale = Q.scale_value;
-    if constexpr (STREAM) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    {  // (both kernels: the plain one keeps them no better -- four of these tests sat in vector lanes once weights mode had added two scalars)
       ArgPtr qp = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+s"(qp));
       pd = qp->diag; pl = qp->loo_i; pp = qp->lppd_i;
       pcount = qp->counters; plist = qp->slow_list; sbase = qp->slow_base; scale = qp->scale_value;
     }
+#endif
     if (handled && t == 0) {
       if (slow) {
         const unsigned long long idx = atomicAdd(&pcount[0], 1ull);
@@ -596,6 +605,9 @@ __device__ __forceinline__ void fit_rows_body(const FitParams& Q) {
       if (lwm) {  // for the output pass: log of the normaliser, tail draws to patch (-1: the general kernel writes this row)
         double* sc_out = const_cast<double*>(Q.ws_s) + sc;
         sc_out[2] = lg;
+        sc_out[3] = khat;     // (the smoothed weight of a rank is min(coef (e^(-khat log1p(-p_j)) - 1) + e_cut, 1): psis.py:153-157)
+        sc_out[6] = coef_s;
+        sc_out[7] = off;
         sc_out[5] = slow ? -1.0 : (smoothed ? (double)n : 0.0);
       }
     }

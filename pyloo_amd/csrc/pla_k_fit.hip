@@ -20,7 +20,7 @@ hipError_t launch_fit(const RowsParams& p, const FastParams& f, int mestM, hipSt
   q.fitted = const_cast<unsigned*>(fitted);  // (behind a streamed pass: only the chunks that pass left)
   q.gave_up = const_cast<unsigned*>(gave_up);
   q.gave_up_total = p.counters + kCounterGaveUp;
-  q.ws_w = p.ws_w;  // (weights mode of the split pass: pla_lwout.h)
+  q.lw_mode = p.lw_split;  // (weights mode of the split pass: pla_lwout.h)
   static const int skip_fit = exp_flag("PLA_SKIP_FIT");  // timing experiments only (experiment builds): the outputs are then garbage
   if (skip_fit) return hipSuccess;
   const int nq = p.ws_stride / 64;

@@ -31,9 +31,9 @@ struct RowsParams {
   // outputs stay compact ([n_obs] = number of selected rows)
   const int64_t* row_index = nullptr;  // (already clamped into the matrix: launch_clamp_rows)
   int ws_sstride = 8;            // doubles per observation in ws_s (16 in the streamed pass: one 128-byte line each)
-  // weights mode of the split pass (rows longer than the registers): [n_obs][ws_stride] smoothed tail weights by descending rank,
-  // written by the fit kernel for lw_output_kernel (pla_lwout.h); null: the fused weights kernels
-  double* ws_w = nullptr;
+  // weights mode of the split pass (rows longer than the registers: selection kernel -> fit kernel -> lw_output_kernel,
+  // pla_lwout.h): the hand-over buffers above are there for it; false: the fused weights kernels
+  bool lw_split = false;
 };
 
 // Streamed split pass: the first kernel (statistics, sweep, selection; HBM stream) on `first` and, BESIDE it on `second`, the

@@ -7,13 +7,16 @@
 //   1. wave_loo_chunked_kernel<T, VEC, CapsMid, SPLIT, LW>: statistics, sweep, selection of the tail -- the LOO pass's kernel
 //      with the sign convention of weights mode, eight waves per CU; hands over the tail's shifted log ratios x and
 //      (max, min, sum e^x, -, cutoff, tail length);
-//   2. fit_rows_kernel (pla_fit.h) with FitParams::ws_w: sorts the tail, fits, smooths, and leaves per observation the SORTED
-//      tail x (descending), the smoothed weight of every rank, log(sum of all weights) and the number of draws to patch;
+//   2. fit_rows_kernel (pla_fit.h) with FitParams::lw_mode: sorts the tail, fits, smooths, and leaves per observation the SORTED
+//      tail x (descending) in place of the hand-over, log(sum of all weights), the number of draws to patch and the three scalars
+//      the smoothed weight of a rank is evaluated from (k-hat, sigma / k-hat, e_cut - sigma / k-hat);
 //   3. this kernel: one wave per observation streams the row once more -- lw = (raw - max raw) - log sum for every draw
 //      (psis.py:134,158) -- and collects the draws above the cutoff (psis.py:139-141: exactly the tail) with their positions;
 //      each of them then finds its descending rank in the sorted tail by bisection (equal draws take consecutive ranks through
 //      a counter per rank: which of them gets which quantile is arbitrary in the reference too, its argsort is unstable,
-//      psis.py:146) and its position is overwritten with log(smoothed weight of that rank) - log sum (psis.py:155-158).
+//      psis.py:146) and its position is overwritten with log(smoothed weight of that rank) - log sum (psis.py:155-158); the
+//      weight of a rank is the fit kernel's own expression evaluated here (the weights by rank read from memory -- a dependent
+//      load behind the bisection -- cost 4 % of the pass).
 // No draw index travels through the selection, the sort or the fit.  Observations whose scalar [5] is negative were put on
 // the list for the general kernel (by the selection or by the fit): that kernel writes their rows, this one skips them.
 #pragma once
@@ -33,17 +36,19 @@ struct LwOutParams {
   int n_draws;
   int64_t stride_obs;   // elements
   const double* ws_y;   // [n_obs][ws_stride] sorted tail x, descending
-  const double* ws_w;   // [n_obs][ws_stride] smoothed weight by descending rank
-  const double* ws_s;   // [n_obs][ws_sstride]: max raw, -, log sum, -, cutoff, tail draws to patch (< 0: not this kernel's row)
+  const double* ws_s;   // [n_obs][ws_sstride]: max raw, -, log sum, k-hat, cutoff, tail draws to patch (< 0: not this kernel's row), sigma / k-hat, e_cut - sigma / k-hat
   int ws_stride;
   int ws_sstride;
+  const double* l1_table;  // [tail_count] log1p(-(j + 0.5) / M) (host-computed, as the fit kernel reads it)
+  int tail_count;
 };
+
 
 struct LwoSmem {                    // per wave: 11.6 KB -> three four-wave workgroups per CU
   double xs[kLwoTail];              // sorted tail
   double lx[kLwoTail + kWave];      // collected tail draws: x ...
   unsigned li[kLwoTail + kWave];    // ... and position in the row
-  unsigned cnt[kLwoTail];           // equal draws: how many took this rank already
+  unsigned cnt[kLwoTail / 2];       // equal draws: how many took this rank already (two 16-bit counters to a word)
 };
 
 template <typename T>
@@ -52,8 +57,13 @@ __global__ __launch_bounds__(kWave * kLwoWaves, 3) void lw_output_kernel(LwOutPa
   typedef int v4i __attribute__((ext_vector_type(4)));
   __shared__ __attribute__((aligned(16))) double lt[2 * kLogTabN];
   __shared__ __attribute__((aligned(16))) LwoSmem smem[kLwoWaves];
+  __shared__ __attribute__((aligned(16))) double tab[2 * kTabN];
+  __shared__ __attribute__((aligned(16))) double l1s[kLwoTail];
   const int tid = threadIdx.x;
   for (int j = tid; j < kLogTabN; j += kWave * kLwoWaves) log_table_entry(lt, j);
+  for (int j = tid; j < kTabN; j += kWave * kLwoWaves) exp_table_entry(tab, j);
+  const int M = P.tail_count;
+  for (int j = tid; j < M; j += kWave * kLwoWaves) l1s[j] = P.l1_table[j];
   __syncthreads();
   const int lane = tid & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -70,14 +80,13 @@ __global__ __launch_bounds__(kWave * kLwoWaves, 3) void lw_output_kernel(LwOutPa
     if (nd < 0.0) continue;  // (wave-uniform: the general kernel writes this row)
     const int n = (int)nd;
     const double m = uniform_d(sc[0]), L = uniform_d(sc[2]), xcut = uniform_d(sc[4]);
+    const double khat = uniform_d(sc[3]), coef_s = uniform_d(sc[6]), off = uniform_d(sc[7]);
+    const double rn = n > 0 ? 1.0 / (double)n : 0.0;
     wave_sync();  // (the row before is done with the lists)
-    const double* ws = P.ws_w + r * (int64_t)P.ws_stride;
     if (n > 0) {
       const double* ys = P.ws_y + r * (int64_t)P.ws_stride;
-      for (int j = lane; j < n; j += kWave) {
-        sm.xs[j] = ys[j];
-        sm.cnt[j] = 0u;
-      }
+      for (int j = lane; j < n; j += kWave) sm.xs[j] = ys[j];
+      for (int j = lane; j < (n + 1) / 2; j += kWave) sm.cnt[j] = 0u;
     }
     const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base + r * P.stride_obs), 0, S * (int)sizeof(T), 0x00020000);
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(obase + r * (int64_t)S, 0, S * (int)sizeof(T), 0x00020000);
@@ -122,11 +131,19 @@ __global__ __launch_bounds__(kWave * kLwoWaves, 3) void lw_output_kernel(LwOutPa
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const bool live = c0 + u * kWave < nt && lo[u] < n;
-          slot[u] = live ? (unsigned)lo[u] + atomicAdd(&sm.cnt[lo[u]], 1u) : (unsigned)n;
+          const unsigned sh = ((unsigned)lo[u] & 1u) << 4;
+          slot[u] = live ? (unsigned)lo[u] + ((atomicAdd(&sm.cnt[lo[u] >> 1], 1u << sh) >> sh) & 0xffffu) : (unsigned)n;
         }
         double w[U];
+        // w_j = min(sigma / k (e^(-k log1p(-p_j)) - 1) + e_cut, 1) with p_j = (j + 0.5) / n, j the ASCENDING index of the rank
+        // (psis.py:153-157,218-221): the fit kernel's own expression (pla_fit.h, smooth()), from the scalars it left
 #pragma unroll
-        for (int u = 0; u < U; ++u) w[u] = ws[slot[u] < (unsigned)n ? slot[u] : 0u];
+        for (int u = 0; u < U; ++u) {
+          const int j = n - 1 - (int)(slot[u] < (unsigned)n ? slot[u] : 0u);
+          const double l1 = (n == M) ? l1s[j] : log_fast(1.0 - ((double)j + 0.5) * rn);
+          const double ez = exp_tab(fmin(-khat * l1, 700.0), tab);
+          w[u] = fmin(fma(ez, coef_s, off), 1.0);
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const unsigned c = c0 + u * kWave;
