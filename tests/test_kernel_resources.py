@@ -155,3 +155,44 @@ def test_streamed_tile_pass_kernels_fit_on_one_cu_together(isa_lines):
         assert ttotal.get("v_writelane_b32", 0) == 0, (tname, dict(ttotal))
     _, _, _, tile = isa_stats.kernel_stats(lines, "tile_loo_kernelIdLb1")
     assert 2 * alloc(tile["NumVgprs"] + tile.get("NumAgprs", 0)) + alloc(fit["NumVgprs"] + fit.get("NumAgprs", 0)) <= 512, (tile, fit)
+
+
+def test_masked_spill_detector_on_hand_written_listings():
+    """`isa_stats.masked_spills` itself: a spill written in uniform code is not reported, one written between a saveexec and
+    the restore of that very mask is, also through an else-branch (s_andn2_saveexec) and with another region nested inside."""
+    import isa_stats
+
+    def listing(body):
+        return ["_ZN3pla6sampleEv:"] + [ln.strip() for ln in body.strip().split("\n")] + [".Lfunc_end0:"]
+
+    uniform = listing("""
+        v_writelane_b32 v9, s4, 0
+        s_and_saveexec_b64 s[2:3], vcc
+        s_cbranch_execz .LBB0_2
+        v_add_f64 v[0:1], v[0:1], v[2:3]
+        .LBB0_2:
+        s_or_b64 exec, exec, s[2:3]
+        v_writelane_b32 v9, s5, 1
+        v_readlane_b32 s4, v9, 0
+    """)
+    assert isa_stats.masked_spills(uniform, "sample") == []
+    masked = listing("""
+        s_and_saveexec_b64 s[2:3], vcc
+        s_cbranch_execz .LBB0_2
+        v_writelane_b32 v9, s4, 0
+        .LBB0_2:
+        s_or_b64 exec, exec, s[2:3]
+        v_readlane_b32 s4, v9, 0
+    """)
+    assert len(isa_stats.masked_spills(masked, "sample")) == 1
+    nested = listing("""
+        s_and_saveexec_b64 s[2:3], vcc
+        s_and_saveexec_b64 s[6:7], s[0:1]
+        v_nop
+        s_or_b64 exec, exec, s[6:7]
+        s_andn2_saveexec_b64 s[2:3], s[2:3]
+        v_writelane_b32 v9, s4, 2
+        s_or_b64 exec, exec, s[2:3]
+        v_writelane_b32 v9, s4, 3
+    """)
+    assert [ln.split()[-1] for ln in isa_stats.masked_spills(nested, "sample")] == ["2"]
