@@ -1497,7 +1497,7 @@ __device__ PLA_ROW_INLINE void wave_loo_row(const RowsParams& P, const FastParam
     if (slow) ws_store_scalars<SYNC>(F, r, lane, 0.0, 0.0, 0.0, 0.0, 0.0, -1.0);
   }
   if constexpr (LW || PLA_WAVE_ABLATE) {
-    if (!streamed && rp_next) issue_row_loads<T, VEC, LW ? 0 : PLA_LOAD_AUX>(v, rp_next, S);  // (weights mode: every row)
+    if (!streamed && rp_next) issue_row_loads<T, VEC, (LW && PLA_LW_RESTREAM) ? 0 : PLA_LOAD_AUX>(v, rp_next, S);  // (weights mode: every row)
   }
   if (lane == 0) {
     if (slow) {
@@ -1583,7 +1583,7 @@ __global__ __launch_bounds__(kWave * CAP::kWaves, PLA_MIN_WAVES_PER_SIMD) void w
     left = kQueueUnit - 1;
     r = (int64_t)chunk0;
   }
-  if (r < n) issue_row_loads<T, VEC, LW ? 0 : PLA_LOAD_AUX>(v, base + PLA_ROW_OFFSET(P, r), P.n_draws);
+  if (r < n) issue_row_loads<T, VEC, (LW && PLA_LW_RESTREAM) ? 0 : PLA_LOAD_AUX>(v, base + PLA_ROW_OFFSET(P, r), P.n_draws);
   // (the unit after the next is asked for BEFORE the last row of the current unit, not behind it: a returning atomic on a
   // counter that 2048 waves share takes 1-3 us under this load, and waiting for it at the end of every unit was 0.8 % of the
   // pass at 16 rows per unit -- with smaller units, which shorten the ragged end of the launch, it was everything: 4 rows per
